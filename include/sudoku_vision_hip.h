@@ -1,0 +1,142 @@
+/*
+ * sudoku_vision_hip.h -- C ABI of libsudokuvision_hip.so, the MI355X (gfx950) implementation of the
+ * sudoku-vision frame -> digits hot path.
+ *
+ * The reference (HueCodes/sudoku-vision) has no FFI: its boundary for this path is a set of Python
+ * call signatures (cv/preprocess.py, cv/grid.py, cv/extract.py, ml/model.py) over cv2 / torch.
+ * Each entry point below names the reference function (file:line under /root/reference) whose
+ * arithmetic it replaces; sudoku-vision_amd/{cv,ml}/ re-expose them under the reference's names
+ * through ctypes.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  Pointers marked [dev] are device (HBM) addresses valid on the
+ *     context's device; [host] are host addresses.  The library never allocates or frees
+ *     caller-visible memory; scratch and packed weights live inside the opaque context.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Every [dev] call is
+ *     asynchronous on that stream; nothing synchronises the device.
+ *   - Return value: SV_OK (0) or a negative sv_status.  sv_last_error() gives the message of the last
+ *     failure on the calling thread.  No C++ exception crosses this boundary.
+ *   - Images are 8-bit, row-major, `pitch` bytes between rows, BGR interleaved when 3-channel
+ *     (what cv2.imread hands the reference, pipeline/run.py:250).
+ *   - A context is bound to one device and is not thread-safe; use one per host thread/stream.
+ */
+#ifndef SUDOKU_VISION_HIP_H
+#define SUDOKU_VISION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sv_ctx sv_ctx;
+
+typedef enum sv_status {
+    SV_OK = 0,
+    SV_ERR_BAD_ARG = -1,      /* null pointer, non-positive size, even kernel size, ... */
+    SV_ERR_HIP = -2,          /* a HIP runtime call failed (message holds hipGetErrorString) */
+    SV_ERR_NO_WEIGHTS = -3,   /* CNN entry point called before sv_load_weights_f32 */
+    SV_ERR_UNSUPPORTED = -4,  /* parameter outside what this build restates (e.g. blur ksize 9) */
+    SV_ERR_DEGENERATE = -5    /* corners do not define a homography (singular system) */
+} sv_status;
+
+#define SV_CNN_PARAMS 421642        /* ml/model.py: count_parameters(DigitCNN()) */
+#define SV_CELLS 81
+#define SV_CELL_PX 784              /* 28*28 */
+#define SV_CLASSES 10
+
+/* ---- library / context ------------------------------------------------------------------------ */
+
+int sv_version(void);                               /* ABI version, currently 1 */
+const char *sv_last_error(void);                    /* thread-local, never NULL */
+
+/* Creates a context on HIP device `device` (replaces nothing: the reference keeps no state except
+ * the model object of pipeline/run.py:98-111). */
+int sv_ctx_create(int device, sv_ctx **out);
+int sv_ctx_destroy(sv_ctx *ctx);
+
+/* Pre-sizes the context's scratch for batches of up to `max_cells` cells so that later calls do
+ * no hipMalloc (needed before hipGraph capture). */
+int sv_ctx_reserve(sv_ctx *ctx, long max_cells);
+
+/* Loads DigitCNN weights: `blob` [host] is the state_dict flattened in key order
+ * conv1.weight[32,1,3,3] conv1.bias[32] conv2.weight[64,32,3,3] conv2.bias[64] fc1.weight[128,3136]
+ * fc1.bias[128] fc2.weight[10,128] fc2.bias[10] = SV_CNN_PARAMS floats.
+ * Replaces model.load_state_dict(...) + model.to(device), pipeline/run.py:101-108.
+ * Synchronous (packs on the host, copies, waits). */
+int sv_load_weights_f32(sv_ctx *ctx, const float *blob);
+
+/* ---- K1: preprocessing (cv/preprocess.py) ----------------------------------------------------- */
+
+/* grayscale(), cv/preprocess.py:15-19 (cv2.cvtColor BGR2GRAY).  n images, `img_stride` bytes apart. */
+int sv_gray_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch,
+               ptrdiff_t img_stride, uint8_t *gray /*dev, n*H*W*/, void *stream);
+
+/* blur(), cv/preprocess.py:22-29 (cv2.GaussianBlur (k,k), sigma 0).  ksize in {1,3,5,7}. */
+int sv_blur_u8(sv_ctx *ctx, const uint8_t *src /*dev, n*H*W*/, int n, int H, int W, int ksize,
+               uint8_t *dst /*dev*/, void *stream);
+
+/* threshold(), cv/preprocess.py:32-54 (cv2.adaptiveThreshold 255, GAUSSIAN_C).  block odd, 3..31.
+ * type_inv: 1 = THRESH_BINARY_INV (preprocess.py:51), 0 = THRESH_BINARY (pipeline/run.py:91-93). */
+int sv_adaptive_threshold_u8(sv_ctx *ctx, const uint8_t *src /*dev, n*H*W*/, int n, int H, int W,
+                             int block, double c, int type_inv, uint8_t *dst /*dev*/, void *stream);
+
+/* preprocess_for_grid_detection(), cv/preprocess.py:57-65: gray -> blur 5 -> threshold(11, 2, INV),
+ * fused in one kernel.  n frames. */
+int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch,
+                     ptrdiff_t img_stride, uint8_t *binary /*dev, n*H*W*/, void *stream);
+
+/* ---- K2: perspective warp + cell extraction (cv/grid.py, cv/extract.py) ------------------------- */
+
+/* Host, fp64.  order_points + inset + cv2.getPerspectiveTransform to (0,0)..(S-1,S-1) + the inverse
+ * warpPerspective takes, cv/grid.py:74-91,111-130.  corners: n*8 floats (x,y)*4 in any order;
+ * minv: n*9 doubles (destination -> source). */
+int sv_corners_to_minv(const float *corners /*host*/, int n, int out_size, float inset_ratio,
+                       double *minv /*host*/);
+
+/* cv2.warpPerspective(image, M, (S,S)), cv/grid.py:131: bilinear, 1/32-px coordinates, 15-bit
+ * weights, constant-0 border.  channels 1 or 3.  One image. */
+int sv_warp_perspective_u8(sv_ctx *ctx, const uint8_t *img /*dev*/, int H, int W, ptrdiff_t pitch,
+                           int channels, const double *minv /*dev, 9*/, int out_size,
+                           uint8_t *dst /*dev, S*S*channels*/, void *stream);
+
+/* extract_cells(), cv/extract.py:13-56: 9x9 split, margin crop, BGR2GRAY, cv2.resize to
+ * cell_size^2.  margin_h/margin_w are the caller's int(cell_h*margin_ratio), int(cell_w*...). */
+int sv_extract_cells_u8(sv_ctx *ctx, const uint8_t *grid /*dev*/, int h, int w, ptrdiff_t pitch,
+                        int channels, int cell_size, int margin_h, int margin_w,
+                        uint8_t *cells /*dev, 81*cell_size^2*/, void *stream);
+
+/* Fused warp_perspective(frame, corners) -> extract_cells(warped) with the reference defaults
+ * (450, inset 0, 28, 0.1): only the 81 40x40 crops are ever warped.  n frames; minv n*9 doubles. */
+int sv_warp_cells_u8(sv_ctx *ctx, const uint8_t *frames /*dev*/, int n, int H, int W, ptrdiff_t pitch,
+                     ptrdiff_t frame_stride, const double *minv /*dev, n*9*/,
+                     uint8_t *cells /*dev, n*81*784*/, void *stream);
+
+/* ---- K3: DigitCNN forward (ml/model.py) --------------------------------------------------------- */
+
+/* DigitCNN.forward, ml/model.py:34-42 (eval mode): x f32 [B,1,28,28] -> logits f32 [B,10].
+ * digits (argmax, pipeline/run.py:142) and conf (softmax[argmax], :141-143) may be NULL. */
+int sv_cnn_forward_f32(sv_ctx *ctx, const float *x /*dev*/, long B, float *logits /*dev, B*10*/,
+                       uint8_t *digits /*dev, B, or NULL*/, float *conf /*dev, B, or NULL*/,
+                       void *stream);
+
+/* The same on 8-bit cells with the reference glue's tensorisation fused in:
+ * x = ((255 - cell)/255 - 0.5)/0.5, pipeline/run.py:126-135 (without preprocess_cell, row N1). */
+int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*784*/, long B,
+                            float *logits /*dev*/, uint8_t *digits /*dev or NULL*/,
+                            float *conf /*dev or NULL*/, void *stream);
+
+/* ---- the whole device-resident path ----------------------------------------------------------- */
+
+/* frames + homographies -> 81 digits per frame: K2 then K3 on `stream`, no host sync.
+ * cells may be NULL (then context scratch is used). */
+int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames /*dev*/, int n, int H, int W,
+                        ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv /*dev, n*9*/,
+                        uint8_t *cells /*dev n*81*784 or NULL*/, float *logits /*dev, n*81*10*/,
+                        uint8_t *digits /*dev, n*81*/, float *conf /*dev n*81 or NULL*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUDOKU_VISION_HIP_H */

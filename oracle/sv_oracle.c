@@ -1,0 +1,477 @@
+/*
+ * sv_oracle.c -- CPU ORACLE for the frame->digits hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The shipped path (sudoku-vision_amd/) never links,
+ * imports or calls anything in oracle/.
+ *
+ * What it restates: the arithmetic behind the call sites in the reference cv modules.  Those files are thin
+ * wrappers over OpenCV (`opencv-python>=4.8`, /root/reference/ml/requirements.txt:3 -- a lower
+ * bound, no lock file), and OpenCV is absent from /root/reference and from this image.  So each
+ * function below restates the PUBLISHED OpenCV 4.8-4.10 CPU algorithm for the call the reference
+ * makes, and cites the reference call site it serves.
+ *
+ * PARITY UNPINNED for everything in this file: the reference holds no golden vector, known-answer
+ * test or fixture for cv2 outputs (its tests assert only len(cells)==81), and cv2 cannot be run
+ * here.  The integer stages (gray, 5x5 blur, warp, resize) follow OpenCV's bit-exact fixed-point
+ * definitions; the one float stage (the 11x11 Gaussian inside adaptiveThreshold) follows the
+ * scalar, non-FMA operation order of OpenCV's FilterEngine -- an AVX2/FMA OpenCV build may differ
+ * from it on pixels whose float mean lies within ~1e-5 of a .5 tie.
+ *
+ * Plain C99, no dependencies beyond libm.  Build: make -C oracle
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint8_t u8;
+
+/* ------------------------------------------------------------------------------------------------
+ * A1  grayscale()  -- reference cv/preprocess.py:15-19 and cv/extract.py:48-49
+ *     cv2.cvtColor(BGR2GRAY) on 8-bit: 15-bit fixed point, coefficients sum to 32768.
+ * ---------------------------------------------------------------------------------------------- */
+static inline u8 gray_px(int b, int g, int r)
+{
+    return (u8)((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15);
+}
+
+void svo_gray_bgr(const u8 *bgr, int H, int W, long pitch, u8 *gray)
+{
+    for (int y = 0; y < H; y++) {
+        const u8 *s = bgr + (long)y * pitch;
+        for (int x = 0; x < W; x++)
+            gray[(long)y * W + x] = gray_px(s[3 * x], s[3 * x + 1], s[3 * x + 2]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A2  blur()  -- reference cv/preprocess.py:22-29: cv2.GaussianBlur(img,(k,k),0) on 8-bit.
+ *     sigma<=0 and k in {1,3,5,7} selects OpenCV's fixed small kernels; the 8-bit path is the
+ *     8.8 fixed-point one: horizontal pass exact in 8.8, vertical pass 16.16 rounded by
+ *     (v + 2^15) >> 16.  Border REFLECT_101 (cv2 BORDER_DEFAULT).
+ * ---------------------------------------------------------------------------------------------- */
+static int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+static const int k_small_fx8[4][7] = {
+    {256, 0, 0, 0, 0, 0, 0},          /* k=1 */
+    {64, 128, 64, 0, 0, 0, 0},        /* k=3: .25 .5 .25 */
+    {16, 64, 96, 64, 16, 0, 0},       /* k=5: 1 4 6 4 1 /16 */
+    {8, 28, 56, 72, 56, 28, 8},       /* k=7: .03125 .109375 .21875 .28125 ... */
+};
+
+/* returns 0 on success, -1 for a kernel size this oracle does not restate */
+int svo_gaussian_blur_u8(const u8 *src, int H, int W, int ksize, u8 *dst)
+{
+    if (ksize != 1 && ksize != 3 && ksize != 5 && ksize != 7) return -1;
+    if (ksize == 1) { memcpy(dst, src, (size_t)H * W); return 0; }
+    const int *k = k_small_fx8[ksize / 2];
+    int r = ksize / 2;
+    uint16_t *tmp = (uint16_t *)malloc((size_t)H * W * sizeof(uint16_t));
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            unsigned s = 0;
+            for (int i = 0; i < ksize; i++) s += (unsigned)k[i] * src[(long)y * W + reflect101(x + i - r, W)];
+            tmp[(long)y * W + x] = (uint16_t)s; /* <= 255*256, no saturation */
+        }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            uint32_t s = 0;
+            for (int i = 0; i < ksize; i++) s += (uint32_t)k[i] * tmp[(long)reflect101(y + i - r, H) * W + x];
+            dst[(long)y * W + x] = (u8)((s + 32768u) >> 16);
+        }
+    free(tmp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Float Gaussian taps as cv2.getGaussianKernel(n, sigma<=0, CV_32F) produces them (OpenCV >= 4.2:
+ * computed in IEEE double in this exact order, then rounded to float).
+ * ---------------------------------------------------------------------------------------------- */
+int svo_gaussian_kernel_f32(int n, float *out)
+{
+    if (n < 1 || (n & 1) == 0 || n > 255) return -1;
+    if (n == 1) { out[0] = 1.f; return 0; }
+    if (n == 3) { out[0] = 0.25f; out[1] = 0.5f; out[2] = 0.25f; return 0; }
+    if (n == 5) { const float t[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f}; memcpy(out, t, sizeof t); return 0; }
+    if (n == 7) { const float t[7] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}; memcpy(out, t, sizeof t); return 0; }
+    double sigma = fma((double)n, 0.15, 0.35);           /* ((n-1)*0.5 - 1)*0.3 + 0.8, one rounding */
+    double scale2x = -0.125 / (sigma * sigma);
+    int n2 = (n - 1) / 2;
+    double vals[128], sum = 0.0;
+    for (int i = 0, x = 1 - n; i < n2; i++, x += 2) {
+        double t = exp((double)(x * x) * scale2x);
+        vals[i] = t;
+        sum += t;
+    }
+    sum *= 2.0;
+    sum += 1.0;
+    double mul1 = 1.0 / sum;
+    for (int i = 0; i < n2; i++) {
+        double t = vals[i] * mul1;
+        out[i] = (float)t;
+        out[n - 1 - i] = (float)t;
+    }
+    out[n2] = (float)(1.0 * mul1);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A3  threshold()  -- reference cv/preprocess.py:32-54 (BINARY_INV) and pipeline/run.py:91-93
+ *     (BINARY): cv2.adaptiveThreshold(img,255,GAUSSIAN_C,type,block,c).
+ *     src -> f32; separable Gaussian (taps above), border REPLICATE; row pass then column pass in
+ *     FilterEngine's scalar order, every multiply and add rounded to f32 separately (no FMA);
+ *     mean = round-half-even -> u8 (saturated); out = LUT[src - mean + 255].
+ *     type: 0 = THRESH_BINARY, 1 = THRESH_BINARY_INV.
+ * ---------------------------------------------------------------------------------------------- */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* one IEEE rounding per operation: this file is built with -ffp-contract=off (oracle/Makefile) */
+static inline float fmul(float a, float b) { return a * b; }
+static inline float fadd(float a, float b) { return a + b; }
+
+int svo_adaptive_mean_u8(const u8 *src, int H, int W, int block, u8 *mean)
+{
+    float k[255];
+    if (block < 3 || svo_gaussian_kernel_f32(block, k) != 0) return -1;
+    int r = block / 2;
+    float *rows = (float *)malloc((size_t)H * W * sizeof(float));
+    for (int y = 0; y < H; y++) {
+        const u8 *s = src + (long)y * W;
+        for (int x = 0; x < W; x++) {
+            float acc;
+            if (block <= 5) { /* SymmRowSmallFilter: centre, then symmetric pairs */
+                acc = fmul((float)s[x], k[r]);
+                for (int j = 1; j <= r; j++) {
+                    float pr = fadd((float)s[clampi(x - j, 0, W - 1)], (float)s[clampi(x + j, 0, W - 1)]);
+                    acc = fadd(acc, fmul(pr, k[r + j]));
+                }
+            } else {          /* RowFilter: taps left to right */
+                acc = fmul(k[0], (float)s[clampi(x - r, 0, W - 1)]);
+                for (int j = 1; j < block; j++)
+                    acc = fadd(acc, fmul(k[j], (float)s[clampi(x + j - r, 0, W - 1)]));
+            }
+            rows[(long)y * W + x] = acc;
+        }
+    }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) { /* SymmColumnFilter: centre (+delta 0), then pairs outward */
+            float acc = fadd(fmul(k[r], rows[(long)y * W + x]), 0.f);
+            for (int j = 1; j <= r; j++) {
+                float pr = fadd(rows[(long)clampi(y + j, 0, H - 1) * W + x], rows[(long)clampi(y - j, 0, H - 1) * W + x]);
+                acc = fadd(acc, fmul(k[r + j], pr));
+            }
+            long m = lrintf(acc); /* round half to even (default FP environment) */
+            mean[(long)y * W + x] = (u8)(m < 0 ? 0 : (m > 255 ? 255 : m));
+        }
+    free(rows);
+    return 0;
+}
+
+int svo_adaptive_threshold_u8(const u8 *src, int H, int W, int block, double c, int type_inv, u8 *dst)
+{
+    u8 *mean = (u8 *)malloc((size_t)H * W);
+    if (svo_adaptive_mean_u8(src, H, W, block, mean) != 0) { free(mean); return -1; }
+    int idelta = type_inv ? (int)floor(c) : (int)ceil(c);
+    u8 tab[768];
+    for (int i = 0; i < 768; i++)
+        tab[i] = type_inv ? (u8)(i - 255 <= -idelta ? 255 : 0) : (u8)(i - 255 > -idelta ? 255 : 0);
+    for (long i = 0; i < (long)H * W; i++) dst[i] = tab[(int)src[i] - (int)mean[i] + 255];
+    free(mean);
+    return 0;
+}
+
+/* A4  preprocess_for_grid_detection() -- reference cv/preprocess.py:57-65: A1 -> A2(5) -> A3(11,2,INV) */
+int svo_preprocess_for_grid_detection(const u8 *bgr, int H, int W, long pitch, u8 *binary)
+{
+    u8 *g = (u8 *)malloc((size_t)H * W), *b = (u8 *)malloc((size_t)H * W);
+    svo_gray_bgr(bgr, H, W, pitch, g);
+    int rc = svo_gaussian_blur_u8(g, H, W, 5, b);
+    if (rc == 0) rc = svo_adaptive_threshold_u8(b, H, W, 11, 2.0, 1, binary);
+    free(g);
+    free(b);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A6  order_points() -- reference cv/grid.py:74-91.  float32 sums/diffs, first index wins ties
+ *     (numpy argmin/argmax).  in: 4 (x,y) pairs; out: TL, TR, BR, BL.
+ * ---------------------------------------------------------------------------------------------- */
+void svo_order_points(const float pts[8], float rect[8])
+{
+    int imin_s = 0, imax_s = 0, imin_d = 0, imax_d = 0;
+    for (int i = 1; i < 4; i++) {
+        float s = pts[2 * i] + pts[2 * i + 1], d = pts[2 * i + 1] - pts[2 * i];
+        if (s < pts[2 * imin_s] + pts[2 * imin_s + 1]) imin_s = i;
+        if (s > pts[2 * imax_s] + pts[2 * imax_s + 1]) imax_s = i;
+        if (d < pts[2 * imin_d + 1] - pts[2 * imin_d]) imin_d = i;
+        if (d > pts[2 * imax_d + 1] - pts[2 * imax_d]) imax_d = i;
+    }
+    const int idx[4] = {imin_s, imin_d, imax_s, imax_d};
+    for (int i = 0; i < 4; i++) { rect[2 * i] = pts[2 * idx[i]]; rect[2 * i + 1] = pts[2 * idx[i] + 1]; }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A7a  cv2.getPerspectiveTransform(src, dst) -- reference cv/grid.py:130.
+ *      8x8 system in double, LU with partial pivoting in OpenCV's operation order, M[8] = 1.
+ *      returns 0 on success, -1 if singular.
+ * ---------------------------------------------------------------------------------------------- */
+int svo_get_perspective_transform(const float src[8], const float dst[8], double M[9])
+{
+    double A[8][8], b[8];
+    for (int i = 0; i < 4; i++) {
+        double sx = src[2 * i], sy = src[2 * i + 1], dx = dst[2 * i], dy = dst[2 * i + 1];
+        A[i][0] = A[i + 4][3] = sx;
+        A[i][1] = A[i + 4][4] = sy;
+        A[i][2] = A[i + 4][5] = 1;
+        A[i][3] = A[i][4] = A[i][5] = A[i + 4][0] = A[i + 4][1] = A[i + 4][2] = 0;
+        A[i][6] = -sx * dx;
+        A[i][7] = -sy * dx;
+        A[i + 4][6] = -sx * dy;
+        A[i + 4][7] = -sy * dy;
+        b[i] = dx;
+        b[i + 4] = dy;
+    }
+    const int m = 8;
+    const double eps = 2.220446049250313e-16 * 100; /* DBL_EPSILON*100 */
+    for (int i = 0; i < m; i++) {
+        int k = i;
+        for (int j = i + 1; j < m; j++)
+            if (fabs(A[j][i]) > fabs(A[k][i])) k = j;
+        if (fabs(A[k][i]) < eps) return -1;
+        if (k != i) {
+            for (int j = i; j < m; j++) { double t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t; }
+            double t = b[i]; b[i] = b[k]; b[k] = t;
+        }
+        double d = -1 / A[i][i];
+        for (int j = i + 1; j < m; j++) {
+            double alpha = A[j][i] * d;
+            for (int kk = i + 1; kk < m; kk++) A[j][kk] += alpha * A[i][kk];
+            b[j] += alpha * b[i];
+        }
+    }
+    for (int i = m - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < m; k++) s -= A[i][k] * b[k];
+        b[i] = s / A[i][i];
+    }
+    for (int i = 0; i < 8; i++) M[i] = b[i];
+    M[8] = 1.0;
+    return 0;
+}
+
+/* 3x3 inverse as cv::invert(DECOMP_LU) does it for 3x3 doubles (cofactors * 1/det). */
+int svo_invert3x3(const double S[9], double D[9])
+{
+    double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+    if (d == 0.) return -1;
+    d = 1. / d;
+    D[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+    D[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+    D[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+    D[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+    D[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+    D[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+    D[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+    D[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+    D[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A7  warp_perspective() host part -- reference cv/grid.py:94-130: order_points, inset toward the
+ *     centroid (float32 numpy arithmetic; inset_ratio 0 leaves the corners bit-identical), dst
+ *     square (0,0)..(S-1,S-1), getPerspectiveTransform, then invert (warpPerspective does this
+ *     itself when WARP_INVERSE_MAP is not set).  Output: Minv (dst -> src), 9 doubles.
+ * ---------------------------------------------------------------------------------------------- */
+int svo_corners_to_minv(const float corners[8], int out_size, float inset_ratio, double Minv[9])
+{
+    float o[8], in[8];
+    svo_order_points(corners, o);
+    /* numpy float32: mean(axis=0) accumulates pairwise in float32 for 4 elements: ((a+b)+(c+d))? no:
+       for n<8 numpy's pairwise sum is a plain left-to-right loop; then divides by 4 (exact). */
+    float cx = (((o[0] + o[2]) + o[4]) + o[6]) / 4.f, cy = (((o[1] + o[3]) + o[5]) + o[7]) / 4.f;
+    for (int i = 0; i < 4; i++) {
+        float dx = cx - o[2 * i], dy = cy - o[2 * i + 1];
+        /* np.linalg.norm on float32[2]: sqrt(dx*dx + dy*dy) in float32 */
+        float dist = sqrtf(fadd(fmul(dx, dx), fmul(dy, dy)));
+        float amt = fmul(dist, inset_ratio);
+        in[2 * i] = fadd(o[2 * i], fmul(dx / dist, amt));
+        in[2 * i + 1] = fadd(o[2 * i + 1], fmul(dy / dist, amt));
+    }
+    const float S = (float)(out_size - 1);
+    const float dst[8] = {0, 0, S, 0, S, S, 0, S};
+    double M[9];
+    if (svo_get_perspective_transform(in, dst, M) != 0) return -1;
+    return svo_invert3x3(M, Minv);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A7b  cv2.warpPerspective(image, M, (S,S))  -- reference cv/grid.py:131.  INTER_LINEAR,
+ *      BORDER_CONSTANT 0.  Source coordinates in double, computed per 64-column block origin
+ *      (X0 at the block's first column, + M0*x1 inside it) exactly as WarpPerspectiveInvoker
+ *      does for a 450-wide destination (block = 64 wide x 16 high when width >= 64); scaled by
+ *      32, rounded half-even to int; integer part >> 5, fraction & 31; four taps with weights
+ *      (32-a)(32-b)*32 etc. (they sum to 32768); out = (sum + 16384) >> 15 per channel; taps
+ *      outside the image contribute 0.
+ * ---------------------------------------------------------------------------------------------- */
+static inline int sat_round_i32(double v)
+{
+    if (v < -2147483648.0) v = -2147483648.0;
+    if (v > 2147483647.0) v = 2147483647.0;
+    return (int)lrint(v); /* half to even */
+}
+
+static inline int sat_s16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+/* block width OpenCV picks for a destination of (dw x dh) */
+static int warp_block_w(int dw, int dh)
+{
+    int bh0 = 16 < dh ? 16 : dh;
+    int bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;
+    return bw0;
+}
+
+void svo_warp_coord(const double Minv[9], int dx, int dy, int bw, int *sx, int *sy, int *a, int *b)
+{
+    int x0 = (dx / bw) * bw, x1 = dx - x0;
+    double X0 = Minv[0] * x0 + Minv[1] * dy + Minv[2];
+    double Y0 = Minv[3] * x0 + Minv[4] * dy + Minv[5];
+    double W0 = Minv[6] * x0 + Minv[7] * dy + Minv[8];
+    double W = W0 + Minv[6] * x1;
+    W = W ? 32. / W : 0;
+    int X = sat_round_i32((X0 + Minv[0] * x1) * W);
+    int Y = sat_round_i32((Y0 + Minv[3] * x1) * W);
+    *sx = sat_s16(X >> 5);
+    *sy = sat_s16(Y >> 5);
+    *a = X & 31;
+    *b = Y & 31;
+}
+
+static inline int tap(const u8 *img, int H, int W, long pitch, int C, int x, int y, int c)
+{
+    if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) return 0;
+    return img[(long)y * pitch + (long)x * C + c];
+}
+
+void svo_warp_pixel(const u8 *img, int H, int W, long pitch, int C, const double Minv[9], int dx, int dy, int bw, u8 *out)
+{
+    int sx, sy, a, b;
+    svo_warp_coord(Minv, dx, dy, bw, &sx, &sy, &a, &b);
+    int w00 = (32 - a) * (32 - b) * 32, w01 = a * (32 - b) * 32, w10 = (32 - a) * b * 32, w11 = a * b * 32;
+    for (int c = 0; c < C; c++) {
+        int v = tap(img, H, W, pitch, C, sx, sy, c) * w00 + tap(img, H, W, pitch, C, sx + 1, sy, c) * w01 +
+                tap(img, H, W, pitch, C, sx, sy + 1, c) * w10 + tap(img, H, W, pitch, C, sx + 1, sy + 1, c) * w11;
+        out[c] = (u8)((v + 16384) >> 15);
+    }
+}
+
+void svo_warp_perspective_u8(const u8 *img, int H, int W, long pitch, int C, const double Minv[9], int out_size, u8 *dst)
+{
+    int bw = warp_block_w(out_size, out_size);
+    for (int dy = 0; dy < out_size; dy++)
+        for (int dx = 0; dx < out_size; dx++)
+            svo_warp_pixel(img, H, W, pitch, C, Minv, dx, dy, bw, dst + ((long)dy * out_size + dx) * C);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * cv2.resize(src,(dw,dh)) INTER_LINEAR on 8-bit, 1 channel -- reference cv/extract.py:52.
+ *      11-bit weights; horizontal pass to int32; vertical pass
+ *      ((b0*(t0>>4))>>16 + (b1*(t1>>4))>>16 + 2) >> 2.  Same size = copy.
+ * ---------------------------------------------------------------------------------------------- */
+static void resize_axis_table(int s_len, int d_len, int *ofs, short *w)
+{
+    double scale = 1. / ((double)d_len / s_len);
+    for (int d = 0; d < d_len; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        ofs[d] = s;
+        w[2 * d] = (short)lrintf((1.f - f) * 2048.f);
+        w[2 * d + 1] = (short)lrintf(f * 2048.f);
+    }
+}
+
+void svo_resize_linear_u8(const u8 *src, int sh, int sw, long spitch, u8 *dst, int dh, int dw)
+{
+    if (sh == dh && sw == dw) {
+        for (int y = 0; y < dh; y++) memcpy(dst + (long)y * dw, src + (long)y * spitch, (size_t)dw);
+        return;
+    }
+    int *xo = (int *)malloc(sizeof(int) * (size_t)(dw + dh)), *yo = xo + dw;
+    short *xa = (short *)malloc(sizeof(short) * 2 * (size_t)(dw + dh)), *ya = xa + 2 * dw;
+    resize_axis_table(sw, dw, xo, xa);
+    resize_axis_table(sh, dh, yo, ya);
+    /* x pass edge rules: sx<0 -> sx=0,f=0 ; sx>=sw-1 -> S[sw-1]*2048 */
+    for (int d = 0; d < dw; d++) {
+        if (xo[d] < 0) { xo[d] = 0; xa[2 * d] = 2048; xa[2 * d + 1] = 0; }
+        if (xo[d] >= sw - 1) { xo[d] = sw - 1; xa[2 * d] = 2048; xa[2 * d + 1] = 0; }
+    }
+    for (int y = 0; y < dh; y++) {
+        int sy0 = clampi(yo[y], 0, sh - 1), sy1 = clampi(yo[y] + 1, 0, sh - 1);
+        int b0 = ya[2 * y], b1 = ya[2 * y + 1];
+        const u8 *S0 = src + (long)sy0 * spitch, *S1 = src + (long)sy1 * spitch;
+        for (int x = 0; x < dw; x++) {
+            int sx = xo[x], sx1 = sx + 1 < sw ? sx + 1 : sx;
+            int t0 = S0[sx] * xa[2 * x] + S0[sx1] * xa[2 * x + 1];
+            int t1 = S1[sx] * xa[2 * x] + S1[sx1] * xa[2 * x + 1];
+            dst[(long)y * dw + x] = (u8)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+    free(xo);
+    free(xa);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A8  extract_cells() -- reference cv/extract.py:13-56.  margin_h/margin_w are the host's
+ *     int(cell_h*margin_ratio) (Python float multiply, truncation).  grid: u8[h,w,C] (C = 1 or 3),
+ *     cells: u8[81, cell_size, cell_size] row-major r*9+c.
+ * ---------------------------------------------------------------------------------------------- */
+void svo_extract_cells(const u8 *grid, int h, int w, long pitch, int C, int cell_size, int margin_h, int margin_w, u8 *cells)
+{
+    int cell_h = h / 9, cell_w = w / 9;
+    int ch = cell_h - 2 * margin_h, cw = cell_w - 2 * margin_w;
+    u8 *g = (u8 *)malloc((size_t)ch * cw);
+    for (int r = 0; r < 9; r++)
+        for (int c = 0; c < 9; c++) {
+            int y1 = r * cell_h + margin_h, x1 = c * cell_w + margin_w;
+            for (int y = 0; y < ch; y++)
+                for (int x = 0; x < cw; x++) {
+                    const u8 *p = grid + (long)(y1 + y) * pitch + (long)(x1 + x) * C;
+                    g[(long)y * cw + x] = C == 3 ? gray_px(p[0], p[1], p[2]) : p[0];
+                }
+            svo_resize_linear_u8(g, ch, cw, cw, cells + (long)(r * 9 + c) * cell_size * cell_size, cell_size, cell_size);
+        }
+    free(g);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K2 as one call: frame + corners -> 81 cells (and, optionally, the 450x450x3 warped image).
+ * This is warp_perspective(image, corners) followed by extract_cells(warped) with the reference's
+ * defaults (output_size 450, inset 0, cell_size 28, margin 0.1 -> 5 px).
+ * ---------------------------------------------------------------------------------------------- */
+int svo_warp_cells(const u8 *bgr, int H, int W, long pitch, const float corners[8], u8 *cells, u8 *warped_or_null)
+{
+    double Minv[9];
+    if (svo_corners_to_minv(corners, 450, 0.f, Minv) != 0) return -1;
+    u8 *warped = warped_or_null ? warped_or_null : (u8 *)malloc(450 * 450 * 3);
+    svo_warp_perspective_u8(bgr, H, W, pitch, 3, Minv, 450, warped);
+    svo_extract_cells(warped, 450, 450, 450 * 3, 3, 28, 5, 5, cells);
+    if (!warped_or_null) free(warped);
+    return 0;
+}
+
+/* H(ii) tensorisation of the reference glue, pipeline/run.py:129-135 without the CLAHE stage (row N1):
+ * x = ((255 - cell)/255 - 0.5)/0.5 in float32, one rounding per operation. */
+void svo_cells_to_input_f32(const u8 *cells, long n, float *x)
+{
+    for (long i = 0; i < n; i++) {
+        float t = (float)(255 - cells[i]) / 255.0f;
+        x[i] = (t - 0.5f) / 0.5f;
+    }
+}

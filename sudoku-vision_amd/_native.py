@@ -1,0 +1,65 @@
+"""ctypes binding of libsudokuvision_hip.so (include/sudoku_vision_hip.h).  Fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsudokuvision_hip.so")
+
+SV_OK = 0
+ERR_NAMES = {-1: "SV_ERR_BAD_ARG", -2: "SV_ERR_HIP", -3: "SV_ERR_NO_WEIGHTS", -4: "SV_ERR_UNSUPPORTED",
+             -5: "SV_ERR_DEGENERATE"}
+
+_p, _i, _l, _d, _f, _pd = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float, C.c_ssize_t
+
+# name -> argtypes; every function returns int unless listed in _RESTYPES
+SIGNATURES = {
+    "sv_version": [],
+    "sv_last_error": [],
+    "sv_ctx_create": [_i, C.POINTER(_p)],
+    "sv_ctx_destroy": [_p],
+    "sv_ctx_reserve": [_p, _l],
+    "sv_load_weights_f32": [_p, _p],
+    "sv_gray_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
+    "sv_blur_u8": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "sv_adaptive_threshold_u8": [_p, _p, _i, _i, _i, _i, _d, _i, _p, _p],
+    "sv_preprocess_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
+    "sv_corners_to_minv": [_p, _i, _i, _f, _p],
+    "sv_warp_perspective_u8": [_p, _p, _i, _i, _pd, _i, _p, _i, _p, _p],
+    "sv_extract_cells_u8": [_p, _p, _i, _i, _pd, _i, _i, _i, _i, _p, _p],
+    "sv_warp_cells_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p],
+    "sv_cnn_forward_f32": [_p, _p, _l, _p, _p, _p, _p],
+    "sv_cnn_forward_cells_u8": [_p, _p, _l, _p, _p, _p, _p],
+    "sv_frames_to_digits": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p, _p, _p, _p],
+}
+_RESTYPES = {"sv_last_error": C.c_char_p}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the HIP library once.  torch is imported first so that the process holds a single HIP
+    runtime (torch's libamdhip64 and the one this library links share a soname)."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C sudoku-vision_amd/csrc`.  There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError = ABI mismatch, let it surface
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != SV_OK:
+        msg = lib().sv_last_error().decode("utf-8", "replace")
+        raise NativeError(f"{what or 'libsudokuvision_hip'}: {ERR_NAMES.get(rc, rc)}: {msg}")

@@ -1,0 +1,147 @@
+// K2 -- cv/grid.py:94-133 (warp_perspective) and cv/extract.py:13-56 (extract_cells) on MI355X.
+//
+//   k_warp_cells       : the fused path.  One workgroup per (frame, cell): warps only the 40x40 crop
+//                        of the 450x450 grid that extract_cells keeps (crop rows/cols 50r+5..50r+44),
+//                        converts it to gray in LDS, and resamples 40->28 with cv2.resize's 11-bit
+//                        fixed-point bilinear.  Bit-identical to warp_perspective + extract_cells.
+//   k_warp_perspective : the full SxS warp (API parity: warp_perspective returns the image).
+//   k_extract_cells    : extract_cells on an arbitrary warped grid image.
+#include "sv_device.h"
+#include "sv_internal.h"
+
+namespace {
+
+constexpr int OUT = 450, CELL = 50, MARGIN = 5, CROP = 40, CS = 28;
+
+// vertical/horizontal bilinear of cv2.resize on a gray crop held in LDS
+__device__ __forceinline__ int resize_px(const u8 *crop, int cw, int sh, int sw, int xo, int xa0, int xa1, int yo, int b0, int b1)
+{
+    int sx = xo, a0 = xa0, a1 = xa1;
+    if (sx < 0) { sx = 0; a0 = 2048; a1 = 0; }
+    if (sx >= sw - 1) { sx = sw - 1; a0 = 2048; a1 = 0; }
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+    const int sy0 = sv_clamp(yo, 0, sh - 1), sy1 = sv_clamp(yo + 1, 0, sh - 1);
+    const int t0 = crop[sy0 * cw + sx] * a0 + crop[sy0 * cw + sx1] * a1;
+    const int t1 = crop[sy1 * cw + sx] * a0 + crop[sy1 * cw + sx1] * a1;
+    return (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+}
+
+__global__ __launch_bounds__(256) void k_warp_cells(const u8 *__restrict__ frames, int H, int W, ptrdiff_t pitch,
+                                                    ptrdiff_t frame_stride, const double *__restrict__ minv,
+                                                    u8 *__restrict__ cells)
+{
+    __shared__ u8 crop[CROP * CROP];
+    __shared__ int tab[CS][3];  // offset, w0, w1 (same table for x and y: the crop is square)
+    __shared__ double M[9];
+
+    const int tid = threadIdx.x;
+    const int cell = blockIdx.x, frame = blockIdx.y;
+    const int r = cell / 9, c = cell - r * 9;
+    const u8 *img = frames + (ptrdiff_t)frame * frame_stride;
+    if (tid < 9) M[tid] = minv[(ptrdiff_t)frame * 9 + tid];
+    if (tid >= 64 && tid < 64 + CS) {
+        int o, w0, w1;
+        sv_resize_axis(CROP, CS, tid - 64, o, w0, w1);
+        tab[tid - 64][0] = o;
+        tab[tid - 64][1] = w0;
+        tab[tid - 64][2] = w1;
+    }
+    __syncthreads();
+
+    const int bw = sv_warp_block_w(OUT, OUT);
+    for (int i = tid; i < CROP * CROP; i += 256) {
+        const int y = i / CROP, x = i - y * CROP;
+        int px[3];
+        sv_warp_px<3>(img, H, W, pitch, M, c * CELL + MARGIN + x, r * CELL + MARGIN + y, bw, px);
+        crop[i] = (u8)sv_gray_px(px[0], px[1], px[2]);
+    }
+    __syncthreads();
+
+    u8 *dst = cells + ((ptrdiff_t)frame * 81 + cell) * (CS * CS);
+    for (int i = tid; i < CS * CS; i += 256) {
+        const int y = i / CS, x = i - y * CS;
+        dst[i] = (u8)resize_px(crop, CROP, CROP, CROP, tab[x][0], tab[x][1], tab[x][2], tab[y][0], tab[y][1], tab[y][2]);
+    }
+}
+
+template <int C>
+__global__ void k_warp_perspective(const u8 *__restrict__ img, int H, int W, ptrdiff_t pitch, const double *__restrict__ minv,
+                                   int S, u8 *__restrict__ dst)
+{
+    __shared__ double M[9];
+    if (threadIdx.x < 9) M[threadIdx.x] = minv[threadIdx.x];
+    __syncthreads();
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= S) return;
+    int px[C];
+    sv_warp_px<C>(img, H, W, pitch, M, dx, dy, sv_warp_block_w(S, S), px);
+#pragma unroll
+    for (int c = 0; c < C; c++) dst[((ptrdiff_t)dy * S + dx) * C + c] = (u8)px[c];
+}
+
+// one workgroup per cell; dynamic LDS: gray crop (ch*cw bytes) then the x and y tables
+__global__ __launch_bounds__(256) void k_extract_cells(const u8 *__restrict__ grid, int h, int w, ptrdiff_t pitch, int C,
+                                                       int cs, int mh, int mw, u8 *__restrict__ cells)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const int cell_h = h / 9, cell_w = w / 9;
+    const int ch = cell_h - 2 * mh, cw = cell_w - 2 * mw;
+    u8 *crop = smem;
+    int *xt = (int *)(smem + ((ch * cw + 15) & ~15));
+    int *yt = xt + 3 * cs;
+    const int tid = threadIdx.x, cell = blockIdx.x, r = cell / 9, c = cell - r * 9;
+    const int y1 = r * cell_h + mh, x1 = c * cell_w + mw;
+    for (int i = tid; i < 2 * cs; i += 256) {
+        int o, w0, w1;
+        const bool isx = i < cs;
+        const int d = isx ? i : i - cs;
+        sv_resize_axis(isx ? cw : ch, cs, d, o, w0, w1);
+        int *t = isx ? xt : yt;
+        t[3 * d] = o;
+        t[3 * d + 1] = w0;
+        t[3 * d + 2] = w1;
+    }
+    for (int i = tid; i < ch * cw; i += 256) {
+        const int y = i / cw, x = i - y * cw;
+        const u8 *p = grid + (ptrdiff_t)(y1 + y) * pitch + (ptrdiff_t)(x1 + x) * C;
+        crop[i] = C == 3 ? (u8)sv_gray_px(p[0], p[1], p[2]) : p[0];
+    }
+    __syncthreads();
+    u8 *dst = cells + (ptrdiff_t)cell * cs * cs;
+    const bool same = (ch == cs && cw == cs);  // cv2.resize to the same size is a copy
+    for (int i = tid; i < cs * cs; i += 256) {
+        const int y = i / cs, x = i - y * cs;
+        dst[i] = same ? crop[i]
+                      : (u8)resize_px(crop, cw, ch, cw, xt[3 * x], xt[3 * x + 1], xt[3 * x + 2], yt[3 * y], yt[3 * y + 1], yt[3 * y + 2]);
+    }
+}
+
+}  // namespace
+
+int svk_warp_cells(const u8 *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, u8 *cells, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_warp_cells, dim3(81, n), dim3(256), 0, s, frames, H, W, pitch, frame_stride, minv, cells);
+    SV_LAUNCH_CHECK("k_warp_cells");
+    return SV_OK;
+}
+
+int svk_warp_perspective(const u8 *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size, u8 *dst, hipStream_t s)
+{
+    dim3 grid((out_size + 127) / 128, out_size);
+    if (channels == 3)
+        hipLaunchKernelGGL(k_warp_perspective<3>, grid, dim3(128), 0, s, img, H, W, pitch, minv, out_size, dst);
+    else
+        hipLaunchKernelGGL(k_warp_perspective<1>, grid, dim3(128), 0, s, img, H, W, pitch, minv, out_size, dst);
+    SV_LAUNCH_CHECK("k_warp_perspective");
+    return SV_OK;
+}
+
+int svk_extract_cells(const u8 *grid, int h, int w, ptrdiff_t pitch, int channels, int cell_size, int margin_h, int margin_w, u8 *cells, hipStream_t s)
+{
+    const int ch = h / 9 - 2 * margin_h, cw = w / 9 - 2 * margin_w;
+    const size_t lds = (size_t)((ch * cw + 15) & ~15) + sizeof(int) * 6 * (size_t)cell_size;
+    if (lds > 64 * 1024) return sv_fail(SV_ERR_UNSUPPORTED, "extract_cells: crop %dx%d -> %d needs %zu B of LDS (max 65536)", ch, cw, cell_size, lds);
+    hipLaunchKernelGGL(k_extract_cells, dim3(81), dim3(256), lds, s, grid, h, w, pitch, channels, cell_size, margin_h, margin_w, cells);
+    SV_LAUNCH_CHECK("k_extract_cells");
+    return SV_OK;
+}

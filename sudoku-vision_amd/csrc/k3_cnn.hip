@@ -1,0 +1,226 @@
+// K3 -- DigitCNN.forward (ml/model.py:34-42, eval mode) on MI355X, fp32 throughout.
+//
+//   k_conv_features : persistent; one workgroup (4 waves) per PAIR of cells.
+//        conv1 (1->32, 3x3, pad 1) + ReLU + 2x2 max-pool on the VALU into zero-bordered 16x16
+//        planes in LDS; conv2 (32->64) as an implicit GEMM on v_mfma_f32_16x16x4_f32:
+//        M = 4 pooling windows x 4 positions, N = 16 output channels, K = 4 input channels of one
+//        3x3 tap per instruction.  A comes straight from the LDS planes (one ds_read_b32 with an
+//        immediate offset per step, no im2col buffer); B (all 288x32 weights a wave needs) stays in
+//        144 VGPRs for the life of the kernel.  The 16x16 accumulator holds the 4 positions of a
+//        pooling window in the 4 registers of one lane, so bias + ReLU + max-pool are 3 v_max and
+//        never leave the lane.  Output: features [cell][window 49][oc 64] f32.
+//   k_fc_head       : fc1 (3136->128) on the same MFMA with cells as M, + ReLU, fc2 (128->10),
+//        argmax (pipeline/run.py:142) and softmax[argmax] (run.py:141-143).
+//
+// Weight images are packed on the host by sv_load_weights_f32 (sv_api.cpp) into exactly the
+// per-lane register order the kernels load.
+#include "sv_device.h"
+#include "sv_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int PLANE = 257;               // 16x16 plane + 1 float of bank skew
+constexpr int C1_CELL = 32 * PLANE;      // conv1 output of one cell
+constexpr int IN_W = 30, IN_CELL = 900;  // zero-padded 30x30 input
+constexpr int FEAT = 3136;
+
+__device__ __forceinline__ float glue_norm(u8 c)
+{
+    // x = ((255 - cell)/255 - 0.5)/0.5, one rounding per operation (pipeline/run.py:129-135)
+    const float t = __fdiv_rn((float)(255 - (int)c), 255.0f);
+    return __fdiv_rn(__fsub_rn(t, 0.5f), 0.5f);
+}
+
+template <bool U8IN>
+__global__ __launch_bounds__(256, 2) void k_conv_features(const void *__restrict__ xin, long B,
+                                                          const float *__restrict__ w1, const float *__restrict__ b1,
+                                                          const float *__restrict__ w2reg, const float *__restrict__ b2,
+                                                          float *__restrict__ feat)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * IN_CELL + 2 * C1_CELL];  // 72,992 B -> 2 workgroups per CU
+    float *in_s = lds;                 // [2][900]
+    float *c1 = lds + 2 * IN_CELL;     // [2][32][257]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np = wave >> 1, par = wave & 1;
+
+    // conv2 weights for this wave's 32 output channels: 144 VGPRs, loaded once
+    float breg[2][72];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int ks = 0; ks < 72; ks++) breg[t][ks] = w2reg[((np * 2 + t) * 72 + ks) * 64 + lane];
+    const float bias2_0 = b2[32 * np + (lane & 15)], bias2_1 = b2[32 * np + 16 + (lane & 15)];
+
+    for (int i = tid; i < 2 * IN_CELL + 2 * C1_CELL; i += 256) lds[i] = 0.f;  // borders stay zero for good
+    __syncthreads();
+
+    const long npairs = (B + 1) / 2;
+    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+        // ---- stage the two 28x28 inputs into the padded tiles
+        for (int i = tid; i < 2 * 784; i += 256) {
+            const int cl = i / 784, p = i - cl * 784, y = p / 28, x = p - y * 28;
+            long cg = pair * 2 + cl;
+            if (cg >= B) cg = B - 1;
+            float v;
+            if (U8IN) v = glue_norm(((const u8 *)xin)[cg * 784 + p]);
+            else v = ((const float *)xin)[cg * 784 + p];
+            in_s[cl * IN_CELL + (y + 1) * IN_W + x + 1] = v;
+        }
+        __syncthreads();
+
+        // ---- conv1 + ReLU + pool: wave w owns output channels 8w..8w+7
+        for (int rnd = 0; rnd < 7; rnd++) {
+            const int idx = rnd * 64 + lane;
+            if (idx < 392) {
+                const int cl = idx / 196, pp = idx - cl * 196, py = pp / 14, px = pp - py * 14;
+                float patch[4][4];
+                const float *src = in_s + cl * IN_CELL + (2 * py) * IN_W + 2 * px;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) patch[i][j] = src[i * IN_W + j];
+                float *dstp = c1 + cl * C1_CELL + (py + 1) * 16 + px + 1;
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    const int oc = wave * 8 + o;
+                    const float *w = w1 + oc * 9;
+                    const float bias = b1[oc];
+                    float m = -3.0e38f;
+#pragma unroll
+                    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                        for (int dx = 0; dx < 2; dx++) {
+                            float acc = bias;
+#pragma unroll
+                            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                                for (int kx = 0; kx < 3; kx++) acc = __builtin_fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
+                            m = fmaxf(m, acc);
+                        }
+                    dstp[oc * PLANE] = fmaxf(m, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- conv2 on MFMA: 25 tiles of 4 pooling windows (2 cells x 49 windows = 98)
+        for (int j = par; j < 25; j += 2) {
+            const int i16 = lane & 15, q = lane >> 4;
+            int g = 4 * j + (i16 >> 2);
+            if (g > 97) g = 97;
+            const int cl = g >= 49 ? 1 : 0, wl = g - 49 * cl, wy = wl / 7, wx = wl - 7 * wy, s = i16 & 3;
+            const float *ap = c1 + cl * C1_CELL + q * 8 * PLANE + (2 * wy + (s >> 1)) * 16 + 2 * wx + (s & 1);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 72; ks++) {
+                const int tap = ks >> 3, icb = ks & 7;
+                const float a = ap[icb * PLANE + (tap / 3) * 16 + (tap % 3)];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[0][ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[1][ks], acc1, 0, 0, 0);
+            }
+            // rows 4q..4q+3 of the tile = the 4 positions of window 4j+q; column = lane&15
+            const int gw = 4 * j + q;
+            if (gw < 98) {
+                const int ocl = gw >= 49 ? 1 : 0, owl = gw - 49 * ocl;
+                const long cg = pair * 2 + ocl;
+                if (cg < B) {
+                    float *o = feat + cg * FEAT + owl * 64 + 32 * np + i16;
+                    o[0] = fmaxf(fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc0[2], acc0[3])) + bias2_0, 0.f);
+                    o[16] = fmaxf(fmaxf(fmaxf(acc1[0], acc1[1]), fmaxf(acc1[2], acc1[3])) + bias2_1, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// 64 cells per workgroup, 16 per wave; K = 3136 in 196 chunks of 16.
+__global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat, long B, const float *__restrict__ w1reg,
+                                                 const float *__restrict__ b1, const float *__restrict__ w2,
+                                                 const float *__restrict__ b2, float *__restrict__ logits,
+                                                 u8 *__restrict__ digits, float *__restrict__ conf)
+{
+    __shared__ float hs[4][16][129];
+    __shared__ float w2s[10][128];
+    __shared__ float lg[4][16][12];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const long cell0 = (long)blockIdx.x * 64 + wave * 16;
+    long crow = cell0 + r;
+    if (crow >= B) crow = B - 1;
+    const f32x4 *ap = (const f32x4 *)(feat + crow * FEAT + 4 * q);
+    const f32x4 *bp = (const f32x4 *)w1reg + lane;
+
+    for (int i = tid; i < 1280; i += 256) w2s[i >> 7][i & 127] = w2[i];
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 2
+    for (int c = 0; c < 196; c++) {
+        const f32x4 a = ap[c * 4];
+        f32x4 b[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) b[t] = bp[(c * 8 + t) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[t][e], acc[t], 0, 0, 0);
+    }
+
+    // acc[t][reg]: cell row 4q+reg, hidden unit 16t + r
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float bias = b1[16 * t + r];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) hs[wave][4 * q + reg][16 * t + r] = fmaxf(acc[t][reg] + bias, 0.f);
+    }
+    __syncthreads();
+
+    // fc2: lane (cell r, class group q) -> classes q, q+4, q+8
+    for (int jj = 0; jj < 3; jj++) {
+        const int j = q + 4 * jj;
+        if (j < 10) {
+            float s = b2[j];
+            for (int n = 0; n < 128; n++) s = __builtin_fmaf(hs[wave][r][n], w2s[j][n], s);
+            lg[wave][r][j] = s;
+            if (cell0 + r < B) logits[(cell0 + r) * 10 + j] = s;
+        }
+    }
+    __syncthreads();
+    if (q == 0 && cell0 + r < B && (digits || conf)) {
+        float best = lg[wave][r][0];
+        int arg = 0;
+        for (int j = 1; j < 10; j++)
+            if (lg[wave][r][j] > best) { best = lg[wave][r][j]; arg = j; }
+        if (digits) digits[cell0 + r] = (u8)arg;
+        if (conf) {
+            float den = 0.f;
+            for (int j = 0; j < 10; j++) den += expf(lg[wave][r][j] - best);
+            conf[cell0 + r] = 1.0f / den;
+        }
+    }
+}
+
+}  // namespace
+
+int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
+{
+    const sv_weights &w = ctx->w;
+    const long npairs = (B + 1) / 2;
+    const int grid = (int)(npairs < 2L * ctx->num_cus ? npairs : 2L * ctx->num_cus);
+    if (x_is_u8)
+        hipLaunchKernelGGL(k_conv_features<true>, dim3(grid), dim3(256), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
+    else
+        hipLaunchKernelGGL(k_conv_features<false>, dim3(grid), dim3(256), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
+    SV_LAUNCH_CHECK("k_conv_features");
+    hipLaunchKernelGGL(k_fc_head, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, ctx->features, B, w.fc1_wreg, w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
+    SV_LAUNCH_CHECK("k_fc_head");
+    return SV_OK;
+}

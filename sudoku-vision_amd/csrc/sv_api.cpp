@@ -1,0 +1,350 @@
+// Host side of libsudokuvision_hip.so: context, weight packing, fp64 homography, argument checks.
+// Everything exported here is declared in include/sudoku_vision_hip.h.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sv_internal.h"
+
+// ---- errors ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int sv_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *sv_last_error(void) { return g_err; }
+extern "C" int sv_version(void) { return 1; }
+
+// ---- context --------------------------------------------------------------------------------------
+extern "C" int sv_ctx_create(int device, sv_ctx **out)
+{
+    if (!out) return sv_fail(SV_ERR_BAD_ARG, "sv_ctx_create: out is NULL");
+    int count = 0;
+    SV_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return sv_fail(SV_ERR_BAD_ARG, "sv_ctx_create: device %d of %d", device, count);
+    SV_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SV_HIP(hipGetDeviceProperties(&prop, device));
+    sv_ctx *c = new sv_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return SV_OK;
+}
+
+static void free_weights(sv_weights &w)
+{
+    float **ps[] = {&w.conv1_w, &w.conv1_b, &w.conv2_wreg, &w.conv2_b, &w.fc1_wreg, &w.fc1_b, &w.fc2_w, &w.fc2_b};
+    for (float **p : ps) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    w.loaded = false;
+}
+
+extern "C" int sv_ctx_destroy(sv_ctx *ctx)
+{
+    if (!ctx) return SV_OK;
+    (void)hipSetDevice(ctx->device);
+    free_weights(ctx->w);
+    if (ctx->features) (void)hipFree(ctx->features);
+    if (ctx->cells) (void)hipFree(ctx->cells);
+    delete ctx;
+    return SV_OK;
+}
+
+int sv_ensure_scratch(sv_ctx *ctx, long cells)
+{
+    if (cells <= ctx->cap_cells) return SV_OK;
+    SV_HIP(hipSetDevice(ctx->device));
+    if (ctx->features) SV_HIP(hipFree(ctx->features));
+    if (ctx->cells) SV_HIP(hipFree(ctx->cells));
+    ctx->features = nullptr;
+    ctx->cells = nullptr;
+    ctx->cap_cells = 0;
+    SV_HIP(hipMalloc((void **)&ctx->features, sizeof(float) * 3136 * (size_t)cells));
+    SV_HIP(hipMalloc((void **)&ctx->cells, (size_t)SV_CELL_PX * (size_t)cells));
+    ctx->cap_cells = cells;
+    return SV_OK;
+}
+
+extern "C" int sv_ctx_reserve(sv_ctx *ctx, long max_cells)
+{
+    if (!ctx || max_cells <= 0) return sv_fail(SV_ERR_BAD_ARG, "sv_ctx_reserve: bad argument");
+    return sv_ensure_scratch(ctx, max_cells);
+}
+
+// ---- weights --------------------------------------------------------------------------------------
+static int upload(float **dst, const std::vector<float> &v)
+{
+    SV_HIP(hipMalloc((void **)dst, v.size() * sizeof(float)));
+    SV_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SV_OK;
+}
+
+extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
+{
+    if (!ctx || !blob) return sv_fail(SV_ERR_BAD_ARG, "sv_load_weights_f32: NULL argument");
+    SV_HIP(hipSetDevice(ctx->device));
+    free_weights(ctx->w);
+    const float *c1w = blob, *c1b = c1w + 288, *c2w = c1b + 32, *c2b = c2w + 18432, *f1w = c2b + 64,
+                *f1b = f1w + 401408, *f2w = f1b + 128, *f2b = f2w + 1280;
+    // conv2: [np][t][ks][lane]; lane -> oc = 32np + 16t + (lane&15), ic = icb + 8*(lane>>4); ks = tap*8 + icb
+    std::vector<float> w2(2 * 2 * 72 * 64);
+    for (int np = 0; np < 2; np++)
+        for (int t = 0; t < 2; t++)
+            for (int ks = 0; ks < 72; ks++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int oc = 32 * np + 16 * t + (lane & 15), tap = ks >> 3, ic = (ks & 7) + 8 * (lane >> 4);
+                    w2[((np * 2 + t) * 72 + ks) * 64 + lane] = c2w[(oc * 32 + ic) * 9 + tap];
+                }
+    // fc1: [chunk][t][lane][e]; feature index k' = 16*chunk + 4*(lane>>4) + e = window*64 + oc;
+    // the reference flattens NCHW: k = oc*49 + window (ml/model.py:38)
+    std::vector<float> f1((size_t)196 * 8 * 64 * 4);
+    for (int c = 0; c < 196; c++)
+        for (int t = 0; t < 8; t++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int e = 0; e < 4; e++) {
+                    const int kp = 16 * c + 4 * (lane >> 4) + e, win = kp >> 6, oc = kp & 63, n = 16 * t + (lane & 15);
+                    f1[(((size_t)c * 8 + t) * 64 + lane) * 4 + e] = f1w[(size_t)n * 3136 + oc * 49 + win];
+                }
+    int rc;
+    if ((rc = upload(&ctx->w.conv1_w, std::vector<float>(c1w, c1w + 288)))) return rc;
+    if ((rc = upload(&ctx->w.conv1_b, std::vector<float>(c1b, c1b + 32)))) return rc;
+    if ((rc = upload(&ctx->w.conv2_wreg, w2))) return rc;
+    if ((rc = upload(&ctx->w.conv2_b, std::vector<float>(c2b, c2b + 64)))) return rc;
+    if ((rc = upload(&ctx->w.fc1_wreg, f1))) return rc;
+    if ((rc = upload(&ctx->w.fc1_b, std::vector<float>(f1b, f1b + 128)))) return rc;
+    if ((rc = upload(&ctx->w.fc2_w, std::vector<float>(f2w, f2w + 1280)))) return rc;
+    if ((rc = upload(&ctx->w.fc2_b, std::vector<float>(f2b, f2b + 10)))) return rc;
+    ctx->w.loaded = true;
+    return SV_OK;
+}
+
+// ---- host math ------------------------------------------------------------------------------------
+// cv2.getGaussianKernel(n, sigma<=0, CV_32F): fixed tables up to 7, else IEEE-double formula.
+void sv_gaussian_taps_f32(int n, float *out)
+{
+    static const float t3[3] = {0.25f, 0.5f, 0.25f}, t5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                       t7[7] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    if (n == 1) { out[0] = 1.f; return; }
+    if (n == 3) { memcpy(out, t3, sizeof t3); return; }
+    if (n == 5) { memcpy(out, t5, sizeof t5); return; }
+    if (n == 7) { memcpy(out, t7, sizeof t7); return; }
+    const double sigma = std::fma((double)n, 0.15, 0.35);
+    const double scale2x = -0.125 / (sigma * sigma);
+    const int half = (n - 1) / 2;
+    std::vector<double> v(half);
+    double sum = 0.0;
+    for (int i = 0, x = 1 - n; i < half; i++, x += 2) {
+        v[i] = std::exp((double)(x * x) * scale2x);
+        sum += v[i];
+    }
+    sum *= 2.0;
+    sum += 1.0;
+    const double inv = 1.0 / sum;
+    for (int i = 0; i < half; i++) out[i] = out[n - 1 - i] = (float)(v[i] * inv);
+    out[half] = (float)inv;
+}
+
+namespace {
+
+// order_points, cv/grid.py:74-91: TL = argmin(x+y), BR = argmax(x+y), TR = argmin(y-x), BL = argmax(y-x)
+void order_points(const float *p, float *o)
+{
+    int lo_s = 0, hi_s = 0, lo_d = 0, hi_d = 0;
+    float s[4], d[4];
+    for (int i = 0; i < 4; i++) { s[i] = p[2 * i] + p[2 * i + 1]; d[i] = p[2 * i + 1] - p[2 * i]; }
+    for (int i = 1; i < 4; i++) {
+        if (s[i] < s[lo_s]) lo_s = i;
+        if (s[i] > s[hi_s]) hi_s = i;
+        if (d[i] < d[lo_d]) lo_d = i;
+        if (d[i] > d[hi_d]) hi_d = i;
+    }
+    const int pick[4] = {lo_s, lo_d, hi_s, hi_d};
+    for (int i = 0; i < 4; i++) { o[2 * i] = p[2 * pick[i]]; o[2 * i + 1] = p[2 * pick[i] + 1]; }
+}
+
+// cv2.getPerspectiveTransform: 8x8 LU with partial pivoting in double, OpenCV's elimination order
+bool perspective_transform(const float *src, const float *dst, double *M)
+{
+    double a[8][9];  // augmented [A | b]
+    for (int i = 0; i < 4; i++) {
+        const double sx = src[2 * i], sy = src[2 * i + 1], dx = dst[2 * i], dy = dst[2 * i + 1];
+        const double r0[9] = {sx, sy, 1, 0, 0, 0, -sx * dx, -sy * dx, dx};
+        const double r1[9] = {0, 0, 0, sx, sy, 1, -sx * dy, -sy * dy, dy};
+        memcpy(a[i], r0, sizeof r0);
+        memcpy(a[i + 4], r1, sizeof r1);
+    }
+    for (int i = 0; i < 8; i++) {
+        int piv = i;
+        for (int j = i + 1; j < 8; j++)
+            if (std::fabs(a[j][i]) > std::fabs(a[piv][i])) piv = j;
+        if (std::fabs(a[piv][i]) < 2.220446049250313e-16 * 100) return false;
+        if (piv != i)
+            for (int j = i; j < 9; j++) std::swap(a[i][j], a[piv][j]);
+        const double d = -1 / a[i][i];
+        for (int j = i + 1; j < 8; j++) {
+            const double alpha = a[j][i] * d;
+            for (int k = i + 1; k < 9; k++) a[j][k] += alpha * a[i][k];
+        }
+    }
+    for (int i = 7; i >= 0; i--) {
+        double s = a[i][8];
+        for (int k = i + 1; k < 8; k++) s -= a[i][k] * a[k][8];
+        a[i][8] = s / a[i][i];
+    }
+    for (int i = 0; i < 8; i++) M[i] = a[i][8];
+    M[8] = 1.0;
+    return true;
+}
+
+// cv::invert for 3x3 doubles: cofactors scaled by 1/det
+bool invert3(const double *S, double *D)
+{
+    double det = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+    if (det == 0.) return false;
+    det = 1. / det;
+    D[0] = (S[4] * S[8] - S[5] * S[7]) * det;
+    D[1] = (S[2] * S[7] - S[1] * S[8]) * det;
+    D[2] = (S[1] * S[5] - S[2] * S[4]) * det;
+    D[3] = (S[5] * S[6] - S[3] * S[8]) * det;
+    D[4] = (S[0] * S[8] - S[2] * S[6]) * det;
+    D[5] = (S[2] * S[3] - S[0] * S[5]) * det;
+    D[6] = (S[3] * S[7] - S[4] * S[6]) * det;
+    D[7] = (S[1] * S[6] - S[0] * S[7]) * det;
+    D[8] = (S[0] * S[4] - S[1] * S[3]) * det;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int sv_corners_to_minv(const float *corners, int n, int out_size, float inset_ratio, double *minv)
+{
+    if (!corners || !minv || n <= 0 || out_size < 2) return sv_fail(SV_ERR_BAD_ARG, "sv_corners_to_minv: bad argument");
+    for (int f = 0; f < n; f++) {
+        float o[8], in[8];
+        order_points(corners + 8 * f, o);
+        // float32 numpy arithmetic of cv/grid.py:113-121
+        const float cx = (((o[0] + o[2]) + o[4]) + o[6]) / 4.f, cy = (((o[1] + o[3]) + o[5]) + o[7]) / 4.f;
+        for (int i = 0; i < 4; i++) {
+            const float dx = cx - o[2 * i], dy = cy - o[2 * i + 1];
+            const float dist = std::sqrt(dx * dx + dy * dy);
+            const float amt = dist * inset_ratio;
+            in[2 * i] = o[2 * i] + (dx / dist) * amt;
+            in[2 * i + 1] = o[2 * i + 1] + (dy / dist) * amt;
+        }
+        const float S = (float)(out_size - 1);
+        const float dst[8] = {0, 0, S, 0, S, S, 0, S};
+        double M[9];
+        if (!perspective_transform(in, dst, M) || !invert3(M, minv + 9 * f))
+            return sv_fail(SV_ERR_DEGENERATE, "sv_corners_to_minv: frame %d: corners do not define a homography", f);
+    }
+    return SV_OK;
+}
+
+// ---- argument checks + dispatch ---------------------------------------------------------------------
+#define REQUIRE(cond, what) \
+    do { if (!(cond)) return sv_fail(SV_ERR_BAD_ARG, "%s: %s", __func__, what); } while (0)
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+extern "C" int sv_gray_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint8_t *gray, void *stream)
+{
+    REQUIRE(ctx && bgr && gray, "NULL argument");
+    REQUIRE(n > 0 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
+    return svk_gray(bgr, n, H, W, pitch, img_stride, gray, S(stream));
+}
+
+extern "C" int sv_blur_u8(sv_ctx *ctx, const uint8_t *src, int n, int H, int W, int ksize, uint8_t *dst, void *stream)
+{
+    REQUIRE(ctx && src && dst, "NULL argument");
+    REQUIRE(n > 0 && H > 0 && W > 0, "bad shape");
+    REQUIRE(ksize > 0 && (ksize & 1), "ksize must be odd and positive");
+    if (ksize > 7) return sv_fail(SV_ERR_UNSUPPORTED, "sv_blur_u8: ksize %d (only 1,3,5,7 are restated bit-exactly)", ksize);
+    return svk_blur(src, n, H, W, ksize, dst, S(stream));
+}
+
+extern "C" int sv_adaptive_threshold_u8(sv_ctx *ctx, const uint8_t *src, int n, int H, int W, int block, double c, int type_inv, uint8_t *dst, void *stream)
+{
+    REQUIRE(ctx && src && dst, "NULL argument");
+    REQUIRE(n > 0 && H > 0 && W > 0, "bad shape");
+    REQUIRE(block > 1 && (block & 1), "block_size must be odd and > 1");
+    if (block > 31) return sv_fail(SV_ERR_UNSUPPORTED, "sv_adaptive_threshold_u8: block_size %d > 31", block);
+    float taps[31];
+    sv_gaussian_taps_f32(block, taps);
+    const int idelta = type_inv ? (int)std::floor(c) : (int)std::ceil(c);
+    return svk_adaptive_threshold(src, n, H, W, block, taps, idelta, type_inv ? 1 : 0, dst, S(stream));
+}
+
+extern "C" int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint8_t *binary, void *stream)
+{
+    REQUIRE(ctx && bgr && binary, "NULL argument");
+    REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
+    return svk_preprocess(bgr, n, H, W, pitch, img_stride, binary, S(stream));
+}
+
+extern "C" int sv_warp_perspective_u8(sv_ctx *ctx, const uint8_t *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size, uint8_t *dst, void *stream)
+{
+    REQUIRE(ctx && img && minv && dst, "NULL argument");
+    REQUIRE(H > 0 && W > 0 && out_size > 0 && out_size < 32768, "bad shape");
+    REQUIRE(channels == 1 || channels == 3, "channels must be 1 or 3");
+    REQUIRE(pitch >= (ptrdiff_t)W * channels, "pitch < row bytes");
+    return svk_warp_perspective(img, H, W, pitch, channels, minv, out_size, dst, S(stream));
+}
+
+extern "C" int sv_extract_cells_u8(sv_ctx *ctx, const uint8_t *grid, int h, int w, ptrdiff_t pitch, int channels, int cell_size, int margin_h, int margin_w, uint8_t *cells, void *stream)
+{
+    REQUIRE(ctx && grid && cells, "NULL argument");
+    REQUIRE(h >= 9 && w >= 9 && cell_size > 0, "bad shape");
+    REQUIRE(channels == 1 || channels == 3, "channels must be 1 or 3");
+    REQUIRE(margin_h >= 0 && margin_w >= 0 && h / 9 - 2 * margin_h > 0 && w / 9 - 2 * margin_w > 0, "margin leaves an empty cell");
+    return svk_extract_cells(grid, h, w, pitch, channels, cell_size, margin_h, margin_w, cells, S(stream));
+}
+
+extern "C" int sv_warp_cells_u8(sv_ctx *ctx, const uint8_t *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, uint8_t *cells, void *stream)
+{
+    REQUIRE(ctx && frames && minv && cells, "NULL argument");
+    REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
+    return svk_warp_cells(frames, n, H, W, pitch, frame_stride, minv, cells, S(stream));
+}
+
+static int cnn_common(sv_ctx *ctx, const void *x, bool u8in, long B, float *logits, uint8_t *digits, float *conf, void *stream)
+{
+    if (!ctx || !x || !logits) return sv_fail(SV_ERR_BAD_ARG, "sv_cnn_forward: NULL argument");
+    if (B <= 0) return sv_fail(SV_ERR_BAD_ARG, "sv_cnn_forward: B = %ld", B);
+    if (!ctx->w.loaded) return sv_fail(SV_ERR_NO_WEIGHTS, "sv_cnn_forward: call sv_load_weights_f32 first");
+    int rc = sv_ensure_scratch(ctx, B);
+    if (rc) return rc;
+    return svk_cnn_forward(ctx, x, u8in, B, logits, digits, conf, S(stream));
+}
+
+extern "C" int sv_cnn_forward_f32(sv_ctx *ctx, const float *x, long B, float *logits, uint8_t *digits, float *conf, void *stream)
+{
+    return cnn_common(ctx, x, false, B, logits, digits, conf, stream);
+}
+
+extern "C" int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells, long B, float *logits, uint8_t *digits, float *conf, void *stream)
+{
+    return cnn_common(ctx, cells, true, B, logits, digits, conf, stream);
+}
+
+extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, uint8_t *cells, float *logits, uint8_t *digits, float *conf, void *stream)
+{
+    REQUIRE(ctx && frames && minv && logits && digits, "NULL argument");
+    REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
+    if (!ctx->w.loaded) return sv_fail(SV_ERR_NO_WEIGHTS, "sv_frames_to_digits: call sv_load_weights_f32 first");
+    const long B = (long)n * SV_CELLS;
+    int rc = sv_ensure_scratch(ctx, B);
+    if (rc) return rc;
+    uint8_t *c = cells ? cells : ctx->cells;
+    if ((rc = svk_warp_cells(frames, n, H, W, pitch, frame_stride, minv, c, S(stream)))) return rc;
+    return svk_cnn_forward(ctx, c, true, B, logits, digits, conf, S(stream));
+}

@@ -1,0 +1,67 @@
+// Internal declarations shared by the translation units of libsudokuvision_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/sudoku_vision_hip.h"
+
+typedef uint8_t u8;
+
+// Packed DigitCNN weights as the kernels consume them (see k3_cnn.hip for the layouts).
+struct sv_weights {
+    float *conv1_w = nullptr;   // [32][9]
+    float *conv1_b = nullptr;   // [32]
+    float *conv2_wreg = nullptr;// [2 np][2 t][72 ks][64 lane]  MFMA B-operand register image
+    float *conv2_b = nullptr;   // [64]
+    float *fc1_wreg = nullptr;  // [196 chunk][8 t][64 lane][4 e] MFMA B-operand register image
+    float *fc1_b = nullptr;     // [128]
+    float *fc2_w = nullptr;     // [10][128]
+    float *fc2_b = nullptr;     // [10]
+    bool loaded = false;
+};
+
+struct sv_ctx {
+    int device = 0;
+    int num_cus = 256;
+    sv_weights w;
+    // grow-only scratch
+    float *features = nullptr;  // [cells][49][64] pooled conv2 output
+    u8 *cells = nullptr;        // [cells][784]
+    long cap_cells = 0;
+};
+
+int sv_fail(int code, const char *fmt, ...);
+
+#define SV_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return sv_fail(SV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define SV_LAUNCH_CHECK(name)                                                                \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess) return sv_fail(SV_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+int sv_ensure_scratch(sv_ctx *ctx, long cells);
+
+// kernel launchers (one per .hip file)
+int svk_gray(const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *gray, hipStream_t s);
+int svk_blur(const u8 *src, int n, int H, int W, int ksize, u8 *dst, hipStream_t s);
+int svk_adaptive_threshold(const u8 *src, int n, int H, int W, int block, const float *taps, int idelta, int type_inv,
+                           u8 *dst, hipStream_t s);
+int svk_preprocess(const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s);
+int svk_warp_perspective(const u8 *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size,
+                         u8 *dst, hipStream_t s);
+int svk_extract_cells(const u8 *grid, int h, int w, ptrdiff_t pitch, int channels, int cell_size, int margin_h,
+                      int margin_w, u8 *cells, hipStream_t s);
+int svk_warp_cells(const u8 *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv,
+                   u8 *cells, hipStream_t s);
+int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf,
+                    hipStream_t s);
+
+// host helpers
+void sv_gaussian_taps_f32(int n, float *out);

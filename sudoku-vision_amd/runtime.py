@@ -1,0 +1,180 @@
+"""Device context and the device-resident entry point of the hot path.
+
+One `Context` per (process, GPU): it owns the packed CNN weights and the scratch the kernels use.
+Tensors are PyTorch-ROCm tensors; the library sees raw pointers and the current HIP stream.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _native
+
+_KEYS = ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
+_SHAPES = ((32, 1, 3, 3), (32,), (64, 32, 3, 3), (64,), (128, 3136), (128,), (10, 128), (10,))
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _native.NativeError("no ROCm GPU visible: the sudoku-vision hot path runs on MI355X only (no CPU fallback)")
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    def __init__(self, device=None):
+        _require_gpu()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        self._h = C.c_void_p()
+        _native.check(_native.lib().sv_ctx_create(self.device.index, C.byref(self._h)), "sv_ctx_create")
+        self._weights_key = None
+
+    def close(self):
+        if self._h:
+            _native.lib().sv_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ------------------------------------------------------------------------------
+    def load_state_dict(self, sd, key=None):
+        """sd: DigitCNN state_dict (ml/model.py) -- tensors or arrays, any device."""
+        parts = []
+        for k, shape in zip(_KEYS, _SHAPES):
+            v = sd[k]
+            v = v.detach().to("cpu", torch.float32).numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)
+            if tuple(v.shape) != shape:
+                raise ValueError(f"{k}: shape {tuple(v.shape)} != {shape}")
+            parts.append(np.ascontiguousarray(v).reshape(-1))
+        blob = np.concatenate(parts)
+        assert blob.size == 421642
+        _native.check(_native.lib().sv_load_weights_f32(self._h, blob.ctypes.data_as(C.c_void_p)), "sv_load_weights_f32")
+        self._weights_key = key
+
+    def reserve(self, max_cells):
+        _native.check(_native.lib().sv_ctx_reserve(self._h, int(max_cells)), "sv_ctx_reserve")
+
+    # ---- K1 -----------------------------------------------------------------------------------
+    def gray(self, bgr):
+        n, H, W = bgr.shape[0], bgr.shape[1], bgr.shape[2]
+        out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        _native.check(_native.lib().sv_gray_u8(self._h, _ptr(bgr), n, H, W, W * 3, H * W * 3, _ptr(out), _stream_ptr()), "sv_gray_u8")
+        return out
+
+    def blur(self, gray, ksize):
+        n, H, W = gray.shape
+        out = torch.empty_like(gray)
+        _native.check(_native.lib().sv_blur_u8(self._h, _ptr(gray), n, H, W, int(ksize), _ptr(out), _stream_ptr()), "sv_blur_u8")
+        return out
+
+    def adaptive_threshold(self, gray, block_size, c, inv=True):
+        n, H, W = gray.shape
+        out = torch.empty_like(gray)
+        _native.check(_native.lib().sv_adaptive_threshold_u8(self._h, _ptr(gray), n, H, W, int(block_size), float(c), int(bool(inv)),
+                                                             _ptr(out), _stream_ptr()), "sv_adaptive_threshold_u8")
+        return out
+
+    def preprocess(self, frames):
+        """frames u8 [n,H,W,3] on device -> binary u8 [n,H,W] (preprocess_for_grid_detection)."""
+        n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
+        return out
+
+    # ---- K2 -----------------------------------------------------------------------------------
+    @staticmethod
+    def corners_to_minv(corners, output_size=450, inset_ratio=0.0):
+        """corners [n,4,2] (host, any order) -> float64 [n,3,3] destination->source homographies (host)."""
+        c = np.ascontiguousarray(np.asarray(corners, dtype=np.float32).reshape(-1, 8))
+        out = np.empty((c.shape[0], 3, 3), np.float64)
+        _native.check(_native.lib().sv_corners_to_minv(c.ctypes.data_as(C.c_void_p), c.shape[0], int(output_size), float(inset_ratio),
+                                                       out.ctypes.data_as(C.c_void_p)), "sv_corners_to_minv")
+        return out
+
+    def minv_to_device(self, minv):
+        return torch.from_numpy(np.ascontiguousarray(minv, np.float64)).to(self.device)
+
+    def warp_perspective(self, img, minv_dev, output_size):
+        H, W = img.shape[0], img.shape[1]
+        ch = 1 if img.dim() == 2 else img.shape[2]
+        shape = (output_size, output_size) if img.dim() == 2 else (output_size, output_size, ch)
+        out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        _native.check(_native.lib().sv_warp_perspective_u8(self._h, _ptr(img), H, W, W * ch, ch, _ptr(minv_dev), int(output_size), _ptr(out),
+                                                           _stream_ptr()), "sv_warp_perspective_u8")
+        return out
+
+    def extract_cells(self, grid, cell_size, margin_h, margin_w):
+        h, w = grid.shape[0], grid.shape[1]
+        ch = 1 if grid.dim() == 2 else grid.shape[2]
+        out = torch.empty((81, cell_size, cell_size), dtype=torch.uint8, device=self.device)
+        _native.check(_native.lib().sv_extract_cells_u8(self._h, _ptr(grid), h, w, w * ch, ch, int(cell_size), int(margin_h), int(margin_w),
+                                                        _ptr(out), _stream_ptr()), "sv_extract_cells_u8")
+        return out
+
+    def warp_cells(self, frames, minv_dev):
+        n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        out = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device)
+        _native.check(_native.lib().sv_warp_cells_u8(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(minv_dev), _ptr(out), _stream_ptr()),
+                      "sv_warp_cells_u8")
+        return out
+
+    # ---- K3 -----------------------------------------------------------------------------------
+    def cnn_forward(self, x, want_digits=False):
+        """x f32 [B,1,28,28] or u8 [B,28,28] cells (glue tensorisation fused) -> logits [B,10] (, digits, conf)."""
+        B = x.shape[0]
+        logits = torch.empty((B, 10), dtype=torch.float32, device=self.device)
+        digits = torch.empty((B,), dtype=torch.uint8, device=self.device) if want_digits else None
+        conf = torch.empty((B,), dtype=torch.float32, device=self.device) if want_digits else None
+        fn = _native.lib().sv_cnn_forward_cells_u8 if x.dtype == torch.uint8 else _native.lib().sv_cnn_forward_f32
+        _native.check(fn(self._h, _ptr(x), B, _ptr(logits), _ptr(digits) if want_digits else None, _ptr(conf) if want_digits else None,
+                         _stream_ptr()), "sv_cnn_forward")
+        return (logits, digits, conf) if want_digits else logits
+
+    # ---- whole path ---------------------------------------------------------------------------
+    def frames_to_digits(self, frames, minv_dev, out=None, keep_cells=False):
+        """frames u8 [n,H,W,3], minv_dev f64 [n,3,3] on device -> dict(logits [n,81,10], digits [n,81], conf [n,81])."""
+        n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        if out is None:
+            out = {"logits": torch.empty((n, 81, 10), dtype=torch.float32, device=self.device),
+                   "digits": torch.empty((n, 81), dtype=torch.uint8, device=self.device),
+                   "conf": torch.empty((n, 81), dtype=torch.float32, device=self.device)}
+            if keep_cells:
+                out["cells"] = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device)
+        cells = out.get("cells")
+        _native.check(_native.lib().sv_frames_to_digits(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(minv_dev),
+                                                        _ptr(cells) if cells is not None else None, _ptr(out["logits"]), _ptr(out["digits"]),
+                                                        _ptr(out["conf"]), _stream_ptr()), "sv_frames_to_digits")
+        return out
+
+
+_default = {}
+_lock = threading.Lock()
+
+
+def default_context(device=None) -> Context:
+    _require_gpu()
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    with _lock:
+        if idx not in _default:
+            _default[idx] = Context(torch.device("cuda", idx))
+        return _default[idx]
+
+
+def frames_to_digits(frames, corners, state_dict=None, ctx=None):
+    """Device-resident hot path: frames u8 [n,H,W,3] (cuda tensor), corners [n,4,2] (host) -> dict of tensors."""
+    ctx = ctx or default_context(frames.device)
+    if state_dict is not None:
+        ctx.load_state_dict(state_dict)
+    minv = ctx.minv_to_device(Context.corners_to_minv(corners))
+    return ctx.frames_to_digits(frames, minv)

@@ -1,0 +1,179 @@
+"""CPU: the C oracle (oracle/sv_oracle.c) against independent float implementations and invariants.
+
+The reference pins no cv2 output (parity unpinned, see the oracle header), so these tests bound the
+oracle from the other side: an independent scipy/numpy float implementation of each stage must agree
+to +-1 LSB, and structural properties the reference's own tests assert (81 cells, 28x28 uint8, binary
+in {0,255}, corner order) must hold.
+"""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+import sv_oracle as o
+
+
+def _img(seed, h, w, c=None):
+    rs = np.random.RandomState(seed)
+    shape = (h, w) if c is None else (h, w, c)
+    base = ndimage.gaussian_filter(rs.uniform(0, 255, shape), 2.0 if c is None else (2.0, 2.0, 0))
+    return np.clip(base * 3 - 255, 0, 255).astype(np.uint8)
+
+
+def test_gray_matches_float_formula():
+    bgr = np.random.RandomState(0).randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    g = o.gray(bgr)
+    f = 0.114 * bgr[..., 0] + 0.587 * bgr[..., 1] + 0.299 * bgr[..., 2]
+    assert np.abs(g.astype(np.float64) - f).max() <= 0.5 + 1e-3
+    # exact points: gray of a gray pixel is itself (coefficients sum to 2^15)
+    v = np.arange(256, dtype=np.uint8)
+    assert (o.gray(np.stack([v, v, v], -1)[None]) == v).all()
+
+
+@pytest.mark.parametrize("k,taps", [(3, [1, 2, 1]), (5, [1, 4, 6, 4, 1]), (7, [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125])])
+def test_blur_matches_scipy_mirror(k, taps):
+    img = _img(1, 41, 67)
+    t = np.asarray(taps, np.float64)
+    t /= t.sum()
+    f = ndimage.convolve1d(ndimage.convolve1d(img.astype(np.float64), t, axis=0, mode="mirror"), t, axis=1, mode="mirror")
+    b = o.gaussian_blur(img, k)
+    assert np.abs(b - np.floor(f + 0.5)).max() <= 1
+    assert (np.abs(b - np.floor(f + 0.5)) > 0).mean() < 0.01
+    assert (o.gaussian_blur(np.full((9, 9), 200, np.uint8), k) == 200).all()   # DC gain exactly 1
+
+
+def test_blur_unsupported_ksize():
+    with pytest.raises(NotImplementedError):
+        o.gaussian_blur(np.zeros((16, 16), np.uint8), 9)
+
+
+def test_gaussian_taps():
+    k = o.gaussian_kernel_f32(11)
+    x = np.arange(-5, 6)
+    ref = np.exp(-x * x / (2 * 2.0 ** 2))
+    ref /= ref.sum()
+    assert np.allclose(k, ref, rtol=0, atol=1e-8)
+    assert (k == k[::-1]).all()
+    # pinned bit patterns (the HIP side computes the same taps on the host; test_abi checks equality)
+    assert [float(v).hex() for v in k[:6]] == ['0x1.20c2560000000p-7', '0x1.bcb86a0000000p-6', '0x1.0ab50a0000000p-4',
+                                               '0x1.f2464c0000000p-4', '0x1.6a7e1e0000000p-3', '0x1.9ac20a0000000p-3']
+
+
+@pytest.mark.parametrize("block", [3, 5, 11, 15])
+def test_adaptive_mean_matches_scipy_nearest(block):
+    img = _img(2, 45, 61)
+    k = o.gaussian_kernel_f32(block).astype(np.float64)
+    f = ndimage.convolve1d(ndimage.convolve1d(img.astype(np.float64), k, axis=1, mode="nearest"), k, axis=0, mode="nearest")
+    m = o.adaptive_mean(img, block)
+    assert np.abs(m - np.rint(f)).max() <= 1
+    assert (m != np.rint(f)).mean() < 0.002
+
+
+def test_adaptive_threshold_rule_and_range():
+    img = _img(3, 40, 50)
+    m = o.adaptive_mean(img, 11).astype(int)
+    inv = o.adaptive_threshold(img, 11, 2, inv=True)
+    binr = o.adaptive_threshold(img, 11, 2, inv=False)
+    assert set(np.unique(inv)) <= {0, 255}
+    assert ((inv == 255) == (img.astype(int) - m <= -2)).all()
+    assert ((binr == 255) == (img.astype(int) - m > -2)).all()
+    # non-integer C: floor for INV, ceil for BINARY (cv2 semantics)
+    assert ((o.adaptive_threshold(img, 11, 2.5, inv=True) == 255) == (img.astype(int) - m <= -2)).all()
+    assert ((o.adaptive_threshold(img, 11, 2.5, inv=False) == 255) == (img.astype(int) - m > -3)).all()
+
+
+def test_order_points():
+    pts = np.array([[400, 90], [90, 100], [95, 410], [420, 400]], np.float32)
+    r = o.order_points(pts)
+    assert r.tolist() == [[90, 100], [400, 90], [420, 400], [95, 410]]
+    assert (o.order_points(pts[::-1]) == r).all()
+
+
+def test_perspective_transform_maps_corners():
+    rs = np.random.RandomState(4)
+    for _ in range(20):
+        src = np.array([[100, 80], [900, 120], [880, 950], [60, 900]], np.float32) + rs.uniform(-40, 40, (4, 2)).astype(np.float32)
+        dst = np.array([[0, 0], [449, 0], [449, 449], [0, 449]], np.float32)
+        M = o.get_perspective_transform(src, dst)
+        p = np.concatenate([src, np.ones((4, 1))], 1).astype(np.float64) @ M.T
+        assert np.abs(p[:, :2] / p[:, 2:] - dst).max() < 1e-8
+        Mi = o.invert3x3(M)
+        assert np.abs(Mi @ M / (Mi @ M)[2, 2] - np.eye(3)).max() < 1e-9
+    with pytest.raises(ValueError):
+        o.get_perspective_transform(np.zeros((4, 2), np.float32), dst)
+
+
+def _float_warp(img, Minv, S):
+    ys, xs = np.mgrid[0:S, 0:S].astype(np.float64)
+    w = Minv[2, 0] * xs + Minv[2, 1] * ys + Minv[2, 2]
+    fx = (Minv[0, 0] * xs + Minv[0, 1] * ys + Minv[0, 2]) / w
+    fy = (Minv[1, 0] * xs + Minv[1, 1] * ys + Minv[1, 2]) / w
+    out = np.stack([ndimage.map_coordinates(img[..., c].astype(np.float64), [fy, fx], order=1, mode="constant", cval=0)
+                    for c in range(img.shape[2])], -1)
+    return out
+
+
+def test_warp_matches_float_bilinear():
+    img = _img(5, 300, 400, 3)
+    corners = np.array([[60, 40], [350, 55], [340, 270], [50, 250]], np.float32)
+    S = 120
+    w = o.warp_perspective(img, corners, S)
+    f = _float_warp(img, o.corners_to_minv(corners, S), S)
+    d = np.abs(w.astype(np.float64) - f)
+    assert d.max() <= 3.0          # 1/32-px coordinate quantisation on a smooth image
+    assert d.mean() < 0.5
+    # identity homography reproduces the image exactly
+    c = np.array([[0, 0], [S - 1, 0], [S - 1, S - 1], [0, S - 1]], np.float32)
+    assert (o.warp_perspective(img[:S, :S], c, S) == img[:S, :S]).all()
+
+
+def test_warp_border_is_zero():
+    img = np.full((50, 50, 3), 200, np.uint8)
+    corners = np.array([[-30, -30], [79, -30], [79, 79], [-30, 79]], np.float32)   # quad larger than the image
+    w = o.warp_perspective(img, corners, 110)
+    assert (w[:25] == 0).all() and (w[40:60, 40:60] == 200).all()
+
+
+def test_resize_matches_float_bilinear_and_copy():
+    img = _img(6, 40, 40)
+    r = o.resize_linear(img, (28, 28))
+    sc = 40 / 28
+    ys = (np.arange(28) + 0.5) * sc - 0.5
+    f = ndimage.map_coordinates(img.astype(np.float64), np.meshgrid(ys, ys, indexing="ij"), order=1, mode="nearest")
+    assert np.abs(r - f).max() <= 1.0
+    assert (o.resize_linear(img, (40, 40)) == img).all()
+    up = o.resize_linear(img[:10, :10], (28, 28))        # upscale: edge clamping path
+    ys = np.clip((np.arange(28) + 0.5) * (10 / 28) - 0.5, 0, 9)
+    fu = ndimage.map_coordinates(img[:10, :10].astype(np.float64), np.meshgrid(ys, ys, indexing="ij"), order=1, mode="nearest")
+    assert np.abs(up - fu).max() <= 1.0
+    assert (o.resize_linear(np.full((40, 40), 77, np.uint8), (28, 28)) == 77).all()
+
+
+def test_extract_cells_structure():
+    grid = _img(7, 450, 450, 3)
+    cells = o.extract_cells(grid)
+    assert cells.shape == (81, 28, 28) and cells.dtype == np.uint8
+    # cell (r,c) depends only on its own 40x40 crop
+    g2 = grid.copy()
+    g2[100:150, 200:250] = 0
+    c2 = o.extract_cells(g2)
+    changed = {i for i in range(81) if (cells[i] != c2[i]).any()}
+    assert changed == {2 * 9 + 4}
+    # gray input, other sizes
+    assert o.extract_cells(o.gray(grid), 32, 0.2).shape == (81, 32, 32)
+    assert (o.extract_cells(np.full((450, 450), 9, np.uint8)) == 9).all()
+
+
+def test_warp_cells_equals_warp_then_extract():
+    from sudoku_vision_amd.synth import synth_frames
+    frames, corners, _ = synth_frames(1, 270, 480, seed=3)
+    f = frames[0].numpy()
+    cells, warped = o.warp_cells(f, corners[0], want_warped=True)
+    assert (warped == o.warp_perspective(f, corners[0])).all()
+    assert (cells == o.extract_cells(warped)).all()
+
+
+def test_glue_tensorisation():
+    c = np.arange(256, dtype=np.uint8)
+    x = o.cells_to_input(c)
+    ref = ((255 - c).astype(np.float32) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5)
+    assert (x == ref).all() and x[0] == 1.0 and x[255] == -1.0

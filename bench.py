@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark of the frame -> digits hot path on MI355X (BASELINE.json metric: frames/s, 1080p -> 81 digits).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic 1080p frames already resident in HBM:
+K1 (frame -> binary image for the host corner search) + K2 (frame + homography -> 81 cells) +
+K3 (cells -> logits, digits).  Workload at every N: BASELINE.json configs[1] per GPU -- 256 synthetic
+1080p frames, fp32 CNN -- with the generator's ground-truth corners (device-only figure; the host
+corner search is reported separately once it is in the loop).  Frames shard by rank with no
+collective (weak scaling); the only torch.distributed use is the timing barrier and a MAX of elapsed.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per unit (restated in DESIGN.md)
+BYTES_PER_FRAME = 9_916_344          # read 6,220,800 + <=1,555,200 ; write 2,073,600 + 63,504 + 3,240
+K1_BYTES_PER_FRAME = 6_220_800 + 2_073_600
+K2_BYTES_PER_FRAME = 1_555_200 + 63_504
+CONV_FLOP_PER_CELL = 451_584 + 7_225_344
+FC_FLOP_PER_CELL = 802_816 + 2_560
+HBM_PEAK = 8.0e12                    # B/s, MI355X_MICROARCH.md
+FP32_MFMA_PEAK = 157.3e12            # FLOP/s, v_mfma_f32_* (= fp32 vector peak)
+
+
+def cpu_baseline(frames_host, corners, sd, threads):
+    """The oracle (CPU port of the reference arithmetic) on a bounded sample: K1+K2 in C, one frame per
+    thread; CNN with torch-CPU on all cells.  Baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    import torch
+    import cnn_oracle
+    import sv_oracle
+    sv_oracle.lib()
+    torch.set_num_threads(threads)
+    n = frames_host.shape[0]
+
+    def one(i):
+        sv_oracle.preprocess_for_grid_detection(frames_host[i])
+        return sv_oracle.warp_cells(frames_host[i], corners[i])
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        cells = list(ex.map(one, range(n)))
+    x = sv_oracle.cells_to_input(np.stack(cells).reshape(-1, 28, 28))[:, None]
+    cnn_oracle.predict(sd, x)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} of the benchmark's synthetic 1080p frames: C oracle K1+K2 (one frame per thread) + torch-CPU DigitCNN, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.synth import synth_frames
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cnn_oracle
+
+    ctx = sva.default_context()
+    n = args.frames
+    H, W = 1080, 1920
+    frames, corners, _ = synth_frames(n, H, W, seed=1234 + rank, device="cuda")
+    sd = cnn_oracle.random_state_dict(1234)        # random-init weights of the DigitCNN architecture
+    ctx.load_state_dict(sd)
+    ctx.reserve(n * 81)
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners))
+    out = {"logits": torch.empty((n, 81, 10), dtype=torch.float32, device="cuda"),
+           "digits": torch.empty((n, 81), dtype=torch.uint8, device="cuda"),
+           "conf": torch.empty((n, 81), dtype=torch.float32, device="cuda")}
+
+    def step():
+        binary = ctx.preprocess(frames)              # K1: what the host corner search consumes
+        ctx.frames_to_digits(frames, minv, out=out)  # K2 -> K3
+        return binary
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_kernel = ctx.timing_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_frames = n * args.steps * world
+        fps = total_frames / elapsed
+        cells = n * 81
+        work = {"k_preprocess_fused": ("hbm", K1_BYTES_PER_FRAME * n), "k_warp_cells": ("hbm", K2_BYTES_PER_FRAME * n),
+                "k_conv_features": ("mfma", CONV_FLOP_PER_CELL * cells), "k_fc_head": ("mfma", FC_FLOP_PER_CELL * cells)}
+        kernels = {}
+        for name, (ms, cnt) in per_kernel.items():
+            if not cnt:
+                continue
+            bound, units = work[name]
+            avg = ms / cnt * 1e-3
+            peak = HBM_PEAK if bound == "hbm" else FP32_MFMA_PEAK
+            ach = units / avg
+            kernels[name] = {"bound": bound, "avg_ms": ms / cnt, "launches": cnt,
+                             "achieved": ach / (1e9 if bound == "hbm" else 1e12), "peak": peak / (1e9 if bound == "hbm" else 1e12),
+                             "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": ach / peak}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(dom)
+        roofline = {"kernel": dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")}, "traffic": traffic}
+        res = {
+            "metric": "end-to-end frames/sec (1080p->81 digits)", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {n} synthetic 1080p frames per GPU per step, HIP threshold + warp + 81-cell CNN fp32 forward, "
+                                   "generator corners (host corner search not in the timed region)",
+                       "frames_per_gpu": n, "height": H, "width": W, "weights": "random-init DigitCNN (seed 1234)",
+                       "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "roofline": roofline,
+            "kernels": kernels,
+            "pipeline_hbm_frac": fps / world * BYTES_PER_FRAME / HBM_PEAK,
+            "pipeline_fp32_frac": fps / world * 81 * (CONV_FLOP_PER_CELL + FC_FLOP_PER_CELL) / FP32_MFMA_PEAK,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            m = min(n, 2 * threads)
+            res["cpu_baseline"] = cpu_baseline(frames[:m].cpu().numpy(), corners[:m], sd, threads)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,6 +60,14 @@ int sv_ctx_destroy(sv_ctx *ctx);
  * no hipMalloc (needed before hipGraph capture). */
 int sv_ctx_reserve(sv_ctx *ctx, long max_cells);
 
+/* Measurement aid (no reference counterpart; pipeline/run.py:247-352 uses time.time()).  Between
+ * sv_timing_begin and sv_timing_end every launch of the four hot kernels is bracketed by hipEvents on
+ * the stream it is launched on.  sv_timing_end waits for those events and returns, per kernel id
+ * 0 = preprocess, 1 = warp_cells, 2 = conv_features, 3 = fc_head: total milliseconds and launches. */
+#define SV_TIMED_KERNELS 4
+int sv_timing_begin(sv_ctx *ctx);
+int sv_timing_end(sv_ctx *ctx, double *ms_total /*host, 4*/, long *launches /*host, 4*/);
+
 /* Loads DigitCNN weights: `blob` [host] is the state_dict flattened in key order
  * conv1.weight[32,1,3,3] conv1.bias[32] conv2.weight[64,32,3,3] conv2.bias[64] fc1.weight[128,3136]
  * fc1.bias[128] fc2.weight[10,128] fc2.bias[10] = SV_CNN_PARAMS floats.

@@ -243,7 +243,7 @@ int svo_get_perspective_transform(const float src[8], const float dst[8], double
         int k = i;
         for (int j = i + 1; j < m; j++)
             if (fabs(A[j][i]) > fabs(A[k][i])) k = j;
-        if (fabs(A[k][i]) < eps) return -1;
+        if (!(fabs(A[k][i]) >= eps)) return -1; /* also rejects NaN */
         if (k != i) {
             for (int j = i; j < m; j++) { double t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t; }
             double t = b[i]; b[i] = b[k]; b[k] = t;

@@ -19,6 +19,8 @@ SIGNATURES = {
     "sv_ctx_destroy": [_p],
     "sv_ctx_reserve": [_p, _l],
     "sv_load_weights_f32": [_p, _p],
+    "sv_timing_begin": [_p],
+    "sv_timing_end": [_p, _p, _p],
     "sv_gray_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
     "sv_blur_u8": [_p, _p, _i, _i, _i, _i, _p, _p],
     "sv_adaptive_threshold_u8": [_p, _p, _i, _i, _i, _i, _d, _i, _p, _p],

@@ -153,11 +153,12 @@ __global__ void k_adaptive_threshold(const u8 *__restrict__ src, int H, int W, F
 
 }  // namespace
 
-int svk_preprocess(const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s)
+int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s)
 {
     Taps11 t;
     sv_gaussian_taps_f32(11, t.k);
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, n);
+    sv_time_scope ts(ctx, SVK_PREPROCESS, s);
     hipLaunchKernelGGL(k_preprocess_fused, grid, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t);
     SV_LAUNCH_CHECK("k_preprocess_fused");
     return SV_OK;

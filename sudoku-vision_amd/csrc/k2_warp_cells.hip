@@ -118,8 +118,9 @@ __global__ __launch_bounds__(256) void k_extract_cells(const u8 *__restrict__ gr
 
 }  // namespace
 
-int svk_warp_cells(const u8 *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, u8 *cells, hipStream_t s)
+int svk_warp_cells(sv_ctx *ctx, const u8 *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, u8 *cells, hipStream_t s)
 {
+    sv_time_scope ts(ctx, SVK_WARP_CELLS, s);
     hipLaunchKernelGGL(k_warp_cells, dim3(81, n), dim3(256), 0, s, frames, H, W, pitch, frame_stride, minv, cells);
     SV_LAUNCH_CHECK("k_warp_cells");
     return SV_OK;

@@ -215,11 +215,15 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *log
     const sv_weights &w = ctx->w;
     const long npairs = (B + 1) / 2;
     const int grid = (int)(npairs < 2L * ctx->num_cus ? npairs : 2L * ctx->num_cus);
+    {
+    sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
     if (x_is_u8)
         hipLaunchKernelGGL(k_conv_features<true>, dim3(grid), dim3(256), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
     else
         hipLaunchKernelGGL(k_conv_features<false>, dim3(grid), dim3(256), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
+    }
     SV_LAUNCH_CHECK("k_conv_features");
+    sv_time_scope ts(ctx, SVK_FC_HEAD, s);
     hipLaunchKernelGGL(k_fc_head, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, ctx->features, B, w.fc1_wreg, w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
     SV_LAUNCH_CHECK("k_fc_head");
     return SV_OK;

@@ -56,6 +56,8 @@ extern "C" int sv_ctx_destroy(sv_ctx *ctx)
     free_weights(ctx->w);
     if (ctx->features) (void)hipFree(ctx->features);
     if (ctx->cells) (void)hipFree(ctx->cells);
+    for (auto &t : ctx->timeline) { (void)hipEventDestroy(t.t0); (void)hipEventDestroy(t.t1); }
+    for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;
     return SV_OK;
 }
@@ -79,6 +81,52 @@ extern "C" int sv_ctx_reserve(sv_ctx *ctx, long max_cells)
 {
     if (!ctx || max_cells <= 0) return sv_fail(SV_ERR_BAD_ARG, "sv_ctx_reserve: bad argument");
     return sv_ensure_scratch(ctx, max_cells);
+}
+
+// ---- per-kernel timing -------------------------------------------------------------------------------
+sv_time_scope::sv_time_scope(sv_ctx *c, int kernel, hipStream_t st) : ctx(c), s(st)
+{
+    if (!ctx || !ctx->timing) return;
+    hipEvent_t e[2];
+    for (auto &ev : e) {
+        if (!ctx->event_pool.empty()) { ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else if (hipEventCreate(&ev) != hipSuccess) return;
+    }
+    (void)hipEventRecord(e[0], s);
+    ctx->timeline.push_back({kernel, e[0], e[1]});
+    idx = (int)ctx->timeline.size() - 1;
+}
+
+sv_time_scope::~sv_time_scope()
+{
+    if (idx >= 0) (void)hipEventRecord(ctx->timeline[idx].t1, s);
+}
+
+extern "C" int sv_timing_begin(sv_ctx *ctx)
+{
+    if (!ctx) return sv_fail(SV_ERR_BAD_ARG, "sv_timing_begin: NULL context");
+    for (auto &t : ctx->timeline) { ctx->event_pool.push_back(t.t0); ctx->event_pool.push_back(t.t1); }
+    ctx->timeline.clear();
+    ctx->timing = true;
+    return SV_OK;
+}
+
+extern "C" int sv_timing_end(sv_ctx *ctx, double *ms_total, long *launches)
+{
+    if (!ctx || !ms_total || !launches) return sv_fail(SV_ERR_BAD_ARG, "sv_timing_end: NULL argument");
+    ctx->timing = false;
+    for (int k = 0; k < SVK_COUNT; k++) { ms_total[k] = 0; launches[k] = 0; }
+    for (auto &t : ctx->timeline) {
+        SV_HIP(hipEventSynchronize(t.t1));
+        float ms = 0;
+        SV_HIP(hipEventElapsedTime(&ms, t.t0, t.t1));
+        ms_total[t.kernel] += ms;
+        launches[t.kernel]++;
+        ctx->event_pool.push_back(t.t0);
+        ctx->event_pool.push_back(t.t1);
+    }
+    ctx->timeline.clear();
+    return SV_OK;
 }
 
 // ---- weights --------------------------------------------------------------------------------------
@@ -187,7 +235,7 @@ bool perspective_transform(const float *src, const float *dst, double *M)
         int piv = i;
         for (int j = i + 1; j < 8; j++)
             if (std::fabs(a[j][i]) > std::fabs(a[piv][i])) piv = j;
-        if (std::fabs(a[piv][i]) < 2.220446049250313e-16 * 100) return false;
+        if (!(std::fabs(a[piv][i]) >= 2.220446049250313e-16 * 100)) return false;  // also rejects NaN
         if (piv != i)
             for (int j = i; j < 9; j++) std::swap(a[i][j], a[piv][j]);
         const double d = -1 / a[i][i];
@@ -288,7 +336,7 @@ extern "C" int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, i
 {
     REQUIRE(ctx && bgr && binary, "NULL argument");
     REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
-    return svk_preprocess(bgr, n, H, W, pitch, img_stride, binary, S(stream));
+    return svk_preprocess(ctx, bgr, n, H, W, pitch, img_stride, binary, S(stream));
 }
 
 extern "C" int sv_warp_perspective_u8(sv_ctx *ctx, const uint8_t *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size, uint8_t *dst, void *stream)
@@ -313,7 +361,7 @@ extern "C" int sv_warp_cells_u8(sv_ctx *ctx, const uint8_t *frames, int n, int H
 {
     REQUIRE(ctx && frames && minv && cells, "NULL argument");
     REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
-    return svk_warp_cells(frames, n, H, W, pitch, frame_stride, minv, cells, S(stream));
+    return svk_warp_cells(ctx, frames, n, H, W, pitch, frame_stride, minv, cells, S(stream));
 }
 
 static int cnn_common(sv_ctx *ctx, const void *x, bool u8in, long B, float *logits, uint8_t *digits, float *conf, void *stream)
@@ -345,6 +393,6 @@ extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, in
     int rc = sv_ensure_scratch(ctx, B);
     if (rc) return rc;
     uint8_t *c = cells ? cells : ctx->cells;
-    if ((rc = svk_warp_cells(frames, n, H, W, pitch, frame_stride, minv, c, S(stream)))) return rc;
+    if ((rc = svk_warp_cells(ctx, frames, n, H, W, pitch, frame_stride, minv, c, S(stream)))) return rc;
     return svk_cnn_forward(ctx, c, true, B, logits, digits, conf, S(stream));
 }

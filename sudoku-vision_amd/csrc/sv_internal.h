@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 
 #include "../../include/sudoku_vision_hip.h"
 
@@ -30,6 +31,20 @@ struct sv_ctx {
     float *features = nullptr;  // [cells][49][64] pooled conv2 output
     u8 *cells = nullptr;        // [cells][784]
     long cap_cells = 0;
+    // optional per-kernel timing (sv_timing_begin/sv_timing_end): hipEvents on the launch stream
+    bool timing = false;
+    struct timed { int kernel; hipEvent_t t0, t1; };
+    std::vector<timed> timeline;
+    std::vector<hipEvent_t> event_pool;
+};
+
+enum sv_kernel_id { SVK_PREPROCESS = 0, SVK_WARP_CELLS = 1, SVK_CONV_FEATURES = 2, SVK_FC_HEAD = 3, SVK_COUNT = 4 };
+
+// RAII bracket: records an event before and after a launch when ctx->timing is on
+struct sv_time_scope {
+    sv_ctx *ctx; hipStream_t s; int idx = -1;
+    sv_time_scope(sv_ctx *c, int kernel, hipStream_t st);
+    ~sv_time_scope();
 };
 
 int sv_fail(int code, const char *fmt, ...);
@@ -53,12 +68,12 @@ int svk_gray(const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_
 int svk_blur(const u8 *src, int n, int H, int W, int ksize, u8 *dst, hipStream_t s);
 int svk_adaptive_threshold(const u8 *src, int n, int H, int W, int block, const float *taps, int idelta, int type_inv,
                            u8 *dst, hipStream_t s);
-int svk_preprocess(const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s);
+int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s);
 int svk_warp_perspective(const u8 *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size,
                          u8 *dst, hipStream_t s);
 int svk_extract_cells(const u8 *grid, int h, int w, ptrdiff_t pitch, int channels, int cell_size, int margin_h,
                       int margin_w, u8 *cells, hipStream_t s);
-int svk_warp_cells(const u8 *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv,
+int svk_warp_cells(sv_ctx *ctx, const u8 *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv,
                    u8 *cells, hipStream_t s);
 int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf,
                     hipStream_t s);

@@ -35,6 +35,11 @@ def extract_cells(grid_image, cell_size: int = 28, margin_ratio: float = 0.1):
     return [host[i].copy() for i in range(81)]
 
 
+def is_cell_empty(cell, threshold: float = 0.02) -> bool:
+    """Otsu-binarised ink ratio below `threshold` (reference cv/extract.py:59-79)."""
+    raise NotImplementedError("is_cell_empty lands with scope row N3 (not on pipeline/run.py's path)")
+
+
 def preprocess_cell_for_model(cell):
     """(1,28,28) float32 in [0,1] (reference cv/extract.py:82-99)."""
     cell = np.asarray(cell)

@@ -65,6 +65,19 @@ class Context:
     def reserve(self, max_cells):
         _native.check(_native.lib().sv_ctx_reserve(self._h, int(max_cells)), "sv_ctx_reserve")
 
+    # ---- per-kernel timing (hipEvents on the launch stream, inside the library) -------------------
+    KERNELS = ("k_preprocess_fused", "k_warp_cells", "k_conv_features", "k_fc_head")
+
+    def timing_begin(self):
+        _native.check(_native.lib().sv_timing_begin(self._h), "sv_timing_begin")
+
+    def timing_end(self):
+        """-> {kernel name: (total ms, launches)}; waits for the recorded events."""
+        ms = (C.c_double * 4)()
+        cnt = (C.c_long * 4)()
+        _native.check(_native.lib().sv_timing_end(self._h, ms, cnt), "sv_timing_end")
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNELS)}
+
     # ---- K1 -----------------------------------------------------------------------------------
     def gray(self, bgr):
         n, H, W = bgr.shape[0], bgr.shape[1], bgr.shape[2]

@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sudoku_vision_hip.h declares; host-only
+entry points (no GPU needed) agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sv_oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    import sudoku_vision_amd as sva
+    if not os.path.exists(sva._native.LIB_PATH):
+        g.build()
+    return sva._native.lib()
+
+
+def test_header_symbols_exported(lib):
+    import sudoku_vision_amd as sva
+    hdr = open(os.path.join(ROOT, "include", "sudoku_vision_hip.h")).read()
+    declared = set(re.findall(r"\b(sv_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(sva._native.SIGNATURES), "ctypes table and header disagree"
+    assert lib.sv_version() == 1
+
+
+def test_corners_to_minv_matches_oracle(lib):
+    import sudoku_vision_amd as sva
+    rs = np.random.RandomState(0)
+    base = np.array([[500, 100], [1400, 90], [1380, 980], [480, 1000]], np.float32)
+    corners = np.stack([np.round(base + rs.uniform(-60, 60, (4, 2))).astype(np.float32)[rs.permutation(4)] for _ in range(16)])
+    got = sva.Context.corners_to_minv(corners)
+    for i in range(16):
+        assert (got[i] == o.corners_to_minv(corners[i])).all()          # bit-exact fp64
+    got = sva.Context.corners_to_minv(corners, 300, 0.05)
+    for i in range(16):
+        assert np.allclose(got[i], o.corners_to_minv(corners[i], 300, 0.05), rtol=1e-12, atol=0)
+
+
+def test_degenerate_corners_error(lib):
+    import sudoku_vision_amd as sva
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_DEGENERATE"):
+        sva.Context.corners_to_minv(np.zeros((1, 4, 2), np.float32))
+
+
+def test_bad_args_return_codes(lib):
+    assert lib.sv_corners_to_minv(None, 1, 450, 0.0, None) == -1
+    assert b"bad argument" in lib.sv_last_error()
+    assert lib.sv_ctx_destroy(None) == 0
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    import sudoku_vision_amd as sva
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sva._native.NativeError, match="no CPU fallback"):
+        sva.default_context()
+    from sudoku_vision_amd.cv.preprocess import preprocess_for_grid_detection
+    with pytest.raises(sva._native.NativeError):
+        preprocess_for_grid_detection(np.zeros((32, 32, 3), np.uint8))
+
+
+def test_dropin_module_names_resolve():
+    """The reference's callers do sys.path.insert(cv/), `from preprocess import ...` (pipeline/run.py:28-35)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from preprocess import preprocess_for_grid_detection, grayscale, blur, threshold;"
+            "from grid import find_grid_contour, warp_perspective, order_points, find_contours, approximate_polygon;"
+            "from extract import extract_cells, is_cell_empty, preprocess_cell_for_model;"
+            "from model import DigitCNN, count_parameters; m = DigitCNN();"
+            "assert count_parameters(m) == 421642;"
+            "assert list(m.state_dict()) == ['conv1.weight','conv1.bias','conv2.weight','conv2.bias','fc1.weight','fc1.bias','fc2.weight','fc2.bias'];"
+            "print('ok')") % (os.path.join(ROOT, "sudoku-vision_amd", "cv"), os.path.join(ROOT, "sudoku-vision_amd", "ml"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr

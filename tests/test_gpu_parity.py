@@ -1,0 +1,190 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Integer/byte stages: bit-exact.  CNN logits: |diff| <= 1e-4 (fp32, north_star tolerance);
+digit indices equal."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cnn_oracle
+import sv_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+
+
+def _frames(n, H, W, seed):
+    from sudoku_vision_amd.synth import synth_frames
+    return synth_frames(n, H, W, seed=seed, device="cuda")
+
+
+@pytest.mark.parametrize("H,W", [(270, 480), (97, 131), (1080, 1920)])
+def test_preprocess_fused_bit_exact(ctx, H, W):
+    frames, _, _ = _frames(2, H, W, seed=H)
+    got = ctx.preprocess(frames).cpu().numpy()
+    host = frames.cpu().numpy()
+    for i in range(2):
+        assert (got[i] == o.preprocess_for_grid_detection(host[i])).all()
+
+
+def test_preprocess_random_noise_bit_exact(ctx):
+    """Pure noise maximises the number of near-tie means and exercises every border path."""
+    rs = np.random.RandomState(5)
+    img = rs.randint(0, 256, (3, 75, 140, 3)).astype(np.uint8)
+    got = ctx.preprocess(torch.from_numpy(img).cuda()).cpu().numpy()
+    for i in range(3):
+        assert (got[i] == o.preprocess_for_grid_detection(img[i])).all()
+
+
+def test_standalone_stages_bit_exact(ctx):
+    rs = np.random.RandomState(6)
+    bgr = rs.randint(0, 256, (2, 61, 83, 3)).astype(np.uint8)
+    d = torch.from_numpy(bgr).cuda()
+    g = ctx.gray(d)
+    assert (g.cpu().numpy() == np.stack([o.gray(b) for b in bgr])).all()
+    for k in (1, 3, 5, 7):
+        assert (ctx.blur(g, k).cpu().numpy() == np.stack([o.gaussian_blur(x, k) for x in g.cpu().numpy()])).all()
+    for block, c, inv in ((3, 2, True), (5, 0, False), (11, 2, True), (11, 2, False), (15, 3.5, True), (31, -1, False)):
+        got = ctx.adaptive_threshold(g, block, c, inv).cpu().numpy()
+        exp = np.stack([o.adaptive_threshold(x, block, c, inv) for x in g.cpu().numpy()])
+        assert (got == exp).all(), (block, c, inv)
+
+
+def test_fused_equals_staged(ctx):
+    frames, _, _ = _frames(1, 200, 300, seed=9)
+    a = ctx.preprocess(frames)
+    b = ctx.adaptive_threshold(ctx.blur(ctx.gray(frames), 5), 11, 2, True)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920)])
+def test_warp_cells_bit_exact(ctx, H, W):
+    import sudoku_vision_amd as sva
+    frames, corners, _ = _frames(3, H, W, seed=W)
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners))
+    got = ctx.warp_cells(frames, minv).cpu().numpy()
+    host = frames.cpu().numpy()
+    for i in range(3):
+        assert (got[i] == o.warp_cells(host[i], corners[i])).all()
+
+
+def test_warp_perspective_and_extract_bit_exact(ctx):
+    import sudoku_vision_amd as sva
+    frames, corners, _ = _frames(1, 540, 960, seed=2)
+    host = frames[0].cpu().numpy()
+    # corners partly outside the frame: constant-0 border taps
+    c2 = corners[0].copy()
+    c2[0] = [-40, -25]
+    for cs, S, inset in ((corners[0], 450, 0.0), (c2, 450, 0.0), (corners[0], 300, 0.0)):
+        minv = ctx.minv_to_device(sva.Context.corners_to_minv(cs[None], S, inset))
+        w = ctx.warp_perspective(frames[0], minv, S)
+        exp = o.warp_perspective(host, cs, S, inset)
+        assert (w.cpu().numpy() == exp).all()
+        for cell_size, margin in ((28, 0.1), (32, 0.2), (28, 0.0)):
+            mh = int((S // 9) * margin)
+            cells = ctx.extract_cells(w, cell_size, mh, mh).cpu().numpy()
+            assert (cells == o.extract_cells(exp, cell_size, margin)).all()
+    # gray input
+    g = ctx.gray(frames)[0]
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners[:1]))
+    wg = ctx.warp_perspective(g, minv, 450)
+    assert (wg.cpu().numpy() == o.warp_perspective(g.cpu().numpy(), corners[0])).all()
+    assert (ctx.extract_cells(wg, 28, 5, 5).cpu().numpy() == o.extract_cells(wg.cpu().numpy())).all()
+
+
+def _check_cnn(ctx, sd, x, want_digits=True):
+    ctx.load_state_dict(sd)
+    logits, digits, conf = ctx.cnn_forward(torch.from_numpy(x).cuda(), want_digits=True)
+    el, ed, ec = cnn_oracle.predict(sd, x if x.dtype != np.uint8 else o.cells_to_input(x)[:, None])
+    diff = np.abs(logits.cpu().numpy() - el.numpy()).max()
+    assert diff <= LOGIT_TOL, diff
+    top2 = np.sort(el.numpy(), 1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2 * LOGIT_TOL          # argmax is only defined up to the logit tolerance
+    assert (digits.cpu().numpy()[clear] == ed.numpy()[clear]).all()
+    assert np.abs(conf.cpu().numpy() - ec.numpy()).max() <= 1e-5
+    return logits, digits
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 81, 200])
+def test_cnn_random_weights(ctx, B):
+    sd = cnn_oracle.random_state_dict(1234)
+    _check_cnn(ctx, sd, cnn_oracle.golden_inputs(B + 7, B))
+
+
+def test_cnn_golden_fixtures(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "cnn_random_seed1234.npz"))
+    sd = cnn_oracle.random_state_dict(int(g["seed"]))
+    logits, digits = _check_cnn(ctx, sd, cnn_oracle.golden_inputs(int(g["x_seed"]), 81))
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() <= LOGIT_TOL
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd2 = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    logits, digits = _check_cnn(ctx, sd2, cnn_oracle.golden_inputs(int(g2["x_seed"]), 162))
+    assert np.abs(logits.cpu().numpy() - g2["logits"]).max() <= LOGIT_TOL
+    assert (digits.cpu().numpy() == g2["digits"]).all()          # trained weights: bit-exact digit indices
+
+
+def test_cnn_u8_cells_entry(ctx):
+    sd = cnn_oracle.random_state_dict(3)
+    cells = np.random.RandomState(8).randint(0, 256, (100, 28, 28)).astype(np.uint8)
+    _check_cnn(ctx, sd, cells)
+
+
+def test_digitcnn_module_dropin(ctx, golden_dir):
+    """model = DigitCNN().to(device); model.load_state_dict(...); model.eval(); model(x)  (pipeline/run.py:98-143)."""
+    from sudoku_vision_amd.ml.model import DigitCNN
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd2 = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    model = DigitCNN().to("cuda")
+    model.load_state_dict(sd2)
+    model.eval()
+    x = torch.from_numpy(cnn_oracle.golden_inputs(int(g2["x_seed"]), 162)).cuda()
+    with torch.no_grad():
+        out = model(x)
+        one = model(x[5:6])
+    assert np.abs(out.cpu().numpy() - g2["logits"]).max() <= LOGIT_TOL
+    assert np.abs(one.cpu().numpy() - g2["logits"][5:6]).max() <= LOGIT_TOL
+    assert (out.argmax(1).cpu().numpy() == g2["digits"]).all()
+    with pytest.raises(RuntimeError):
+        model(x.cpu())
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(x)
+
+
+def test_frames_to_digits_end_to_end(ctx, golden_dir):
+    import sudoku_vision_amd as sva
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    frames, corners, _ = _frames(4, 1080, 1920, seed=77)
+    ctx.load_state_dict(sd)
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners))
+    out = ctx.frames_to_digits(frames, minv, keep_cells=True)
+    host = frames.cpu().numpy()
+    for i in range(4):
+        cells = o.warp_cells(host[i], corners[i])
+        assert (out["cells"][i].cpu().numpy() == cells).all()
+        el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(cells)[:, None])
+        assert np.abs(out["logits"][i].cpu().numpy() - el.numpy()).max() <= LOGIT_TOL
+        assert (out["digits"][i].cpu().numpy() == ed.numpy()).all()
+
+
+def test_dropin_numpy_functions(ctx):
+    """numpy in -> numpy out through the reference-named functions, in the reference's call order."""
+    from sudoku_vision_amd.cv.preprocess import preprocess_for_grid_detection, grayscale, blur, threshold
+    from sudoku_vision_amd.cv.grid import warp_perspective
+    from sudoku_vision_amd.cv.extract import extract_cells
+    frames, corners, _ = _frames(1, 360, 640, seed=21)
+    img = frames[0].cpu().numpy()
+    binary = preprocess_for_grid_detection(img)
+    assert isinstance(binary, np.ndarray) and binary.dtype == np.uint8 and binary.shape == (360, 640)
+    assert (binary == o.preprocess_for_grid_detection(img)).all()
+    assert (threshold(blur(grayscale(img), ksize=5), block_size=11, c=2) == binary).all()
+    g = grayscale(img)
+    assert grayscale(g) is g
+    warped = warp_perspective(img, corners[0][[2, 0, 3, 1]].astype(np.int32))      # any corner order, int input
+    assert warped.shape == (450, 450, 3) and (warped == o.warp_perspective(img, corners[0])).all()
+    cells = extract_cells(warped)
+    assert isinstance(cells, list) and len(cells) == 81 and all(c.shape == (28, 28) and c.dtype == np.uint8 for c in cells)
+    assert (np.stack(cells) == o.extract_cells(warped)).all()

@@ -50,13 +50,19 @@ def cpu_baseline(frames_host, corners, sd, threads):
         return sv_oracle.warp_cells(frames_host[i], corners[i])
 
     t0 = time.perf_counter()
+    passes = 0
     with ThreadPoolExecutor(threads) as ex:
-        cells = list(ex.map(one, range(n)))
-    x = sv_oracle.cells_to_input(np.stack(cells).reshape(-1, 28, 28))[:, None]
-    cnn_oracle.predict(sd, x)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} of the benchmark's synthetic 1080p frames: C oracle K1+K2 (one frame per thread) + torch-CPU DigitCNN, {dt:.1f} s"}
+        while True:                                   # bounded sample: whole passes until >= 10 s of wall time
+            cells = list(ex.map(one, range(n)))
+            x = sv_oracle.cells_to_input(np.stack(cells).reshape(-1, 28, 28))[:, None]
+            cnn_oracle.predict(sd, x)
+            passes += 1
+            dt = time.perf_counter() - t0
+            if dt >= 10.0 or passes >= 50:
+                break
+    return {"value": n * passes / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{passes} pass(es) over {n} of the benchmark's synthetic 1080p frames ({n * passes} frame evaluations, {dt:.1f} s): "
+                      "C oracle K1+K2, one frame per thread, + torch-CPU DigitCNN on the same threads"}
 
 
 def main():
@@ -128,7 +134,7 @@ def main():
         total_frames = n * args.steps * world
         fps = total_frames / elapsed
         cells = n * 81
-        work = {"k_preprocess_fused": ("hbm", K1_BYTES_PER_FRAME * n), "k_warp_cells": ("hbm", K2_BYTES_PER_FRAME * n),
+        work = {"k_preprocess": ("hbm", K1_BYTES_PER_FRAME * n), "k_warp_cells": ("hbm", K2_BYTES_PER_FRAME * n),
                 "k_conv_features": ("mfma", CONV_FLOP_PER_CELL * cells), "k_fc_head": ("mfma", FC_FLOP_PER_CELL * cells)}
         kernels = {}
         for name, (ms, cnt) in per_kernel.items():

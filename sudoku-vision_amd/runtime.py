@@ -66,7 +66,7 @@ class Context:
         _native.check(_native.lib().sv_ctx_reserve(self._h, int(max_cells)), "sv_ctx_reserve")
 
     # ---- per-kernel timing (hipEvents on the launch stream, inside the library) -------------------
-    KERNELS = ("k_preprocess_fused", "k_warp_cells", "k_conv_features", "k_fc_head")
+    KERNELS = ("k_preprocess", "k_warp_cells", "k_conv_features", "k_fc_head")
 
     def timing_begin(self):
         _native.check(_native.lib().sv_timing_begin(self._h), "sv_timing_begin")

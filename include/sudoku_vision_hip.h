@@ -38,7 +38,8 @@ typedef enum sv_status {
     SV_ERR_HIP = -2,          /* a HIP runtime call failed (message holds hipGetErrorString) */
     SV_ERR_NO_WEIGHTS = -3,   /* CNN entry point called before sv_load_weights_f32 */
     SV_ERR_UNSUPPORTED = -4,  /* parameter outside what this build restates (e.g. blur ksize 9) */
-    SV_ERR_DEGENERATE = -5    /* corners do not define a homography (singular system) */
+    SV_ERR_DEGENERATE = -5,   /* corners do not define a homography (singular system) */
+    SV_ERR_BUFFER = -6        /* caller-provided output buffer too small (required sizes are reported) */
 } sv_status;
 
 #define SV_CNN_PARAMS 421642        /* ml/model.py: count_parameters(DigitCNN()) */
@@ -94,6 +95,34 @@ int sv_adaptive_threshold_u8(sv_ctx *ctx, const uint8_t *src /*dev, n*H*W*/, int
  * fused in one kernel.  n frames. */
 int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch,
                      ptrdiff_t img_stride, uint8_t *binary /*dev, n*H*W*/, void *stream);
+
+/* ---- host corner search (cv/grid.py:16-71; stays on the CPU, no context, no GPU) ----------------- */
+
+/* find_grid_contour(binary, min_area_ratio), cv/grid.py:37-71, with approximate_polygon's
+ * epsilon_ratio (:24-34): external contours (cv2.findContours RETR_EXTERNAL/CHAIN_APPROX_SIMPLE), largest
+ * first, the first one >= min_area_ratio*H*W whose cv2.approxPolyDP(epsilon_ratio*perimeter) has 4
+ * vertices.  binary [host].  Returns 1 and corners[8] = (x,y)*4 in approxPolyDP order, 0 if none
+ * (the reference returns None), or a negative sv_status. */
+int sv_find_grid_corners_u8(const uint8_t *binary /*host*/, int H, int W, ptrdiff_t pitch,
+                            double min_area_ratio, double epsilon_ratio, int *corners /*host, 8*/);
+
+/* The same for n images on `threads` host threads; found[i] = 1/0. */
+int sv_find_grid_corners_batch_u8(const uint8_t *binary /*host*/, int n, int H, int W, ptrdiff_t pitch,
+                                  ptrdiff_t img_stride, double min_area_ratio, double epsilon_ratio,
+                                  int *corners /*host, n*8*/, uint8_t *found /*host, n*/, int threads);
+
+/* find_contours(), cv/grid.py:16-21.  Contours in cv2's order, concatenated: points = (x,y) pairs,
+ * sizes[i] = vertices of contour i.  If a buffer is too small (or NULL) returns SV_ERR_BUFFER with
+ * the required counts in n_points / n_contours. */
+int sv_find_contours_u8(const uint8_t *binary /*host*/, int H, int W, ptrdiff_t pitch,
+                        int *points /*host, cap_points*2*/, long cap_points, int *sizes /*host*/,
+                        int cap_contours, long *n_points, int *n_contours);
+
+/* cv2.contourArea / cv2.arcLength / cv2.approxPolyDP on int32 (x,y) vertices (cv/grid.py:31-33,58,61). */
+int sv_contour_area_i32(const int *xy /*host*/, int n, double *area);
+int sv_arc_length_i32(const int *xy /*host*/, int n, int closed, double *length);
+int sv_approx_poly_dp_i32(const int *xy /*host*/, int n, double epsilon, int closed,
+                          int *out /*host, n*2*/, int *n_out);
 
 /* ---- K2: perspective warp + cell extraction (cv/grid.py, cv/extract.py) ------------------------- */
 

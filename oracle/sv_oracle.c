@@ -475,3 +475,313 @@ void svo_cells_to_input_f32(const u8 *cells, long n, float *x)
         x[i] = (t - 0.5f) / 0.5f;
     }
 }
+
+/* ================================================================================================
+ * A5  host corner search -- reference cv/grid.py:16-71.
+ *     cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)   grid.py:18-20
+ *     cv2.contourArea                                        grid.py:58,61
+ *     cv2.arcLength(closed) / cv2.approxPolyDP(closed)       grid.py:31-33
+ *     find_grid_contour: contours sorted by area (descending, stable), first one with area >=
+ *     min_area_ratio*H*W whose approximation has 4 vertices                       grid.py:37-71
+ *  Restates OpenCV's Suzuki-Abe border follower (legacy C implementation, which the 4.x C++ rewrite
+ *  reproduces): image thresholded to 0/1 and zero-padded by one pixel; raster scan; an outer border
+ *  starts at a 0->1 step whose last marked pixel on the row (lnbd) is <= 0; borders are followed
+ *  8-connected, clockwise search from the direction of arrival, traced pixels are marked 2, or -126
+ *  when the border leaves them to the right; CHAIN_APPROX_SIMPLE keeps the points where the chain
+ *  code changes.  Contours are reported last-found-first (OpenCV inserts each new contour at the head
+ *  of its parent's child list).  PARITY UNPINNED like the rest of this file.
+ * ============================================================================================== */
+
+typedef struct { int *xy; long n, cap; } svo_ptvec;
+
+static void pv_push(svo_ptvec *v, int x, int y)
+{
+    if (v->n == v->cap) {
+        v->cap = v->cap ? v->cap * 2 : 64;
+        v->xy = (int *)realloc(v->xy, sizeof(int) * 2 * (size_t)v->cap);
+    }
+    v->xy[2 * v->n] = x;
+    v->xy[2 * v->n + 1] = y;
+    v->n++;
+}
+
+static const int svo_code_dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+static const int svo_code_dy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+/* icvFetchContour for an outer border, CHAIN_APPROX_SIMPLE; (px,py) in unpadded coordinates */
+static void svo_fetch_contour(signed char *i0, int step, int px, int py, svo_ptvec *out)
+{
+    int deltas[16];
+    for (int k = 0; k < 8; k++) deltas[k] = deltas[k + 8] = svo_code_dy[k] * step + svo_code_dx[k];
+    signed char *i1, *i3, *i4 = 0;
+    int s = 4, s_end = 4, prev_s;
+    do {
+        s = (s - 1) & 7;
+        i1 = i0 + deltas[s];
+    } while (*i1 == 0 && s != s_end);
+    if (s == s_end) { /* single pixel */
+        *i0 = (signed char)(2 | -128);
+        pv_push(out, px, py);
+        return;
+    }
+    i3 = i0;
+    prev_s = s ^ 4;
+    for (;;) {
+        s_end = s;
+        if (s > 15) s = 15;
+        while (s < 15) {
+            i4 = i3 + deltas[++s];
+            if (*i4 != 0) break;
+        }
+        s &= 7;
+        if ((unsigned)(s - 1) < (unsigned)s_end) *i3 = (signed char)(2 | -128);
+        else if (*i3 == 1) *i3 = 2;
+        if (s != prev_s) {
+            pv_push(out, px, py);
+            prev_s = s;
+        }
+        px += svo_code_dx[s];
+        py += svo_code_dy[s];
+        if (i4 == i0 && i3 == i1) break;
+        i3 = i4;
+        s = (s + 4) & 7;
+    }
+}
+
+/* Returns the number of contours; *pts = concatenated (x,y) pairs, *sizes = points per contour, both
+ * malloc'ed, in cv2's order (last found first). */
+int svo_find_contours(const u8 *bin, int H, int W, long pitch, int **pts, int **sizes, long *total_points)
+{
+    const int step = W + 2, ph = H + 2;
+    signed char *img0 = (signed char *)calloc((size_t)step * ph, 1);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) img0[(long)(y + 1) * step + x + 1] = bin[(long)y * pitch + x] ? 1 : 0;
+    svo_ptvec all = {0, 0, 0};
+    int *starts = 0, ncont = 0, capc = 0;
+    int lnbd_x = 0;
+    for (int y = 1; y < ph - 1; y++) {
+        signed char *img = img0 + (long)y * step;
+        int prev = 0;
+        lnbd_x = 0;
+        for (int x = 1; x < step - 1; x++) {
+            int p = img[x];
+            if (p == prev) continue;
+            if (prev == 0 && p == 1) {
+                if (!(img[lnbd_x] > 0)) { /* outer border not inside an already-traced one */
+                    if (ncont == capc) { capc = capc ? capc * 2 : 256; starts = (int *)realloc(starts, sizeof(int) * (size_t)(capc + 1)); }
+                    starts[ncont++] = (int)all.n;
+                    lnbd_x = x;
+                    svo_fetch_contour(img + x, step, x - 1, y - 1, &all);
+                    p = img[x];
+                }
+            }
+            /* holes (1->0 etc.) are never followed in RETR_EXTERNAL */
+            prev = p;
+            if (prev & -2) lnbd_x = x;
+        }
+    }
+    free(img0);
+    *pts = (int *)malloc(sizeof(int) * 2 * (size_t)(all.n ? all.n : 1));
+    *sizes = (int *)malloc(sizeof(int) * (size_t)(ncont ? ncont : 1));
+    long w = 0;
+    for (int c = ncont - 1; c >= 0; c--) { /* last found first */
+        long b = starts[c], e = c + 1 < ncont ? starts[c + 1] : all.n;
+        (*sizes)[ncont - 1 - c] = (int)(e - b);
+        memcpy(*pts + 2 * w, all.xy + 2 * b, sizeof(int) * 2 * (size_t)(e - b));
+        w += e - b;
+    }
+    *total_points = all.n;
+    free(all.xy);
+    free(starts);
+    return ncont;
+}
+
+void svo_free(void *p) { free(p); }
+
+double svo_contour_area(const int *xy, int n)
+{
+    if (n == 0) return 0.;
+    double a = 0;
+    float px = (float)xy[2 * (n - 1)], py = (float)xy[2 * (n - 1) + 1];
+    for (int i = 0; i < n; i++) {
+        float x = (float)xy[2 * i], y = (float)xy[2 * i + 1];
+        a += (double)px * y - (double)py * x;
+        px = x;
+        py = y;
+    }
+    return fabs(a * 0.5);
+}
+
+double svo_arc_length(const int *xy, int n, int closed)
+{
+    if (n <= 1) return 0.;
+    double per = 0;
+    int last = closed ? n - 1 : 0;
+    float px = (float)xy[2 * last], py = (float)xy[2 * last + 1];
+    for (int i = 0; i < n; i++) {
+        float x = (float)xy[2 * i], y = (float)xy[2 * i + 1];
+        float dx = x - px, dy = y - py;
+        per += sqrtf(dx * dx + dy * dy);
+        px = x;
+        py = y;
+    }
+    return per;
+}
+
+/* cv2.approxPolyDP on integer points (Douglas-Peucker, OpenCV's closed-curve start-point search and
+ * final collinear clean-up).  dst must hold n points; returns the new count. */
+int svo_approx_poly_dp(const int *src, int count0, double eps, int closed0, int *dst)
+{
+    typedef struct { int start, end; } range;
+    if (count0 == 0) return 0;
+    size_t cap = (size_t)count0 * 2 + 16;
+    range *stack = (range *)malloc(sizeof(range) * cap);
+    size_t top = 0;
+    int init_iters = 3, count = count0, new_count = 0, pos = 0, wpos, i, j;
+    int is_closed = closed0, le_eps = 0;
+    range slice = {0, 0}, right_slice = {0, 0};
+    int sx = -1000000, sy = -1000000, ex = 0, ey = 0, ptx = 0, pty = 0;
+#define RD(px_, py_, pos_) do { px_ = src[2 * (pos_)]; py_ = src[2 * (pos_) + 1]; if (++(pos_) >= count) (pos_) = 0; } while (0)
+#define RDD(px_, py_, pos_) do { px_ = dst[2 * (pos_)]; py_ = dst[2 * (pos_) + 1]; if (++(pos_) >= count) (pos_) = 0; } while (0)
+#define WR(px_, py_) do { dst[2 * new_count] = px_; dst[2 * new_count + 1] = py_; new_count++; } while (0)
+    eps *= eps;
+    if (!is_closed) {
+        right_slice.start = count;
+        ex = src[0]; ey = src[1];
+        sx = src[2 * (count - 1)]; sy = src[2 * (count - 1) + 1];
+        if (sx != ex || sy != ey) {
+            slice.start = 0;
+            slice.end = count - 1;
+            stack[top++] = slice;
+        } else {
+            is_closed = 1;
+            init_iters = 1;
+        }
+    }
+    if (is_closed) {
+        right_slice.start = 0;
+        for (i = 0; i < init_iters; i++) {
+            double dist, max_dist = 0;
+            pos = (pos + right_slice.start) % count;
+            RD(sx, sy, pos);
+            for (j = 1; j < count; j++) {
+                double dx, dy;
+                RD(ptx, pty, pos);
+                dx = ptx - sx;
+                dy = pty - sy;
+                dist = dx * dx + dy * dy;
+                if (dist > max_dist) { max_dist = dist; right_slice.start = j; }
+            }
+            le_eps = max_dist <= eps;
+        }
+        if (!le_eps) {
+            right_slice.end = slice.start = pos % count;
+            slice.end = right_slice.start = (right_slice.start + slice.start) % count;
+            stack[top++] = right_slice;
+            stack[top++] = slice;
+        } else
+            WR(sx, sy);
+    }
+    while (top > 0) {
+        slice = stack[--top];
+        ex = src[2 * slice.end]; ey = src[2 * slice.end + 1];
+        pos = slice.start;
+        RD(sx, sy, pos);
+        if (pos != slice.end) {
+            double dx = ex - sx, dy = ey - sy, dist, max_dist = 0;
+            while (pos != slice.end) {
+                RD(ptx, pty, pos);
+                dist = fabs((pty - sy) * dx - (ptx - sx) * dy);
+                if (dist > max_dist) { max_dist = dist; right_slice.start = (pos + count - 1) % count; }
+            }
+            le_eps = max_dist * max_dist <= eps * (dx * dx + dy * dy);
+        } else {
+            le_eps = 1;
+            sx = src[2 * slice.start]; sy = src[2 * slice.start + 1];
+        }
+        if (le_eps) WR(sx, sy);
+        else {
+            right_slice.end = slice.end;
+            slice.end = right_slice.start;
+            if (top + 2 > cap) { cap *= 2; stack = (range *)realloc(stack, sizeof(range) * cap); }
+            stack[top++] = right_slice;
+            stack[top++] = slice;
+        }
+    }
+    if (!is_closed) WR(src[2 * (count - 1)], src[2 * (count - 1) + 1]);
+    /* clean-up of (almost) collinear points */
+    is_closed = closed0;
+    count = new_count;
+    pos = is_closed ? count - 1 : 0;
+    RDD(sx, sy, pos);
+    wpos = pos;
+    RDD(ptx, pty, pos);
+    for (i = !is_closed; i < count - !is_closed && new_count > 2; i++) {
+        double dx, dy, dist, sip;
+        RDD(ex, ey, pos);
+        dx = ex - sx;
+        dy = ey - sy;
+        dist = fabs((ptx - sx) * dy - (pty - sy) * dx);
+        sip = (double)(ptx - sx) * (ex - ptx) + (double)(pty - sy) * (ey - pty);
+        if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+            new_count--;
+            dst[2 * wpos] = sx = ex; dst[2 * wpos + 1] = sy = ey;
+            if (++wpos >= count) wpos = 0;
+            RDD(ptx, pty, pos);
+            i++;
+            continue;
+        }
+        dst[2 * wpos] = sx = ptx; dst[2 * wpos + 1] = sy = pty;
+        if (++wpos >= count) wpos = 0;
+        ptx = ex; pty = ey;
+    }
+    if (!is_closed) { dst[2 * wpos] = ptx; dst[2 * wpos + 1] = pty; }
+#undef RD
+#undef RDD
+#undef WR
+    free(stack);
+    return new_count;
+}
+
+/* find_grid_contour, cv/grid.py:37-71.  Returns 1 and the 4 approximated vertices (in approxPolyDP's
+ * order), or 0 when no quadrilateral qualifies. */
+int svo_find_grid_contour(const u8 *bin, int H, int W, long pitch, double min_area_ratio, double epsilon_ratio, int corners[8])
+{
+    int *pts, *sizes;
+    long total;
+    int n = svo_find_contours(bin, H, W, pitch, &pts, &sizes, &total);
+    int found = 0;
+    if (n > 0) {
+        double *area = (double *)malloc(sizeof(double) * (size_t)n);
+        long *off = (long *)malloc(sizeof(long) * (size_t)n);
+        int *order = (int *)malloc(sizeof(int) * (size_t)n);
+        double min_area = min_area_ratio * ((double)H * W);
+        long o = 0;
+        int m = 0;
+        /* The reference sorts ALL contours by area (stable, descending) and stops at the first one below
+         * min_area; only the contours >= min_area can be visited, in that same relative order. */
+        for (int i = 0; i < n; i++) {
+            off[i] = o;
+            area[i] = svo_contour_area(pts + 2 * o, sizes[i]);
+            o += sizes[i];
+            if (area[i] >= min_area) order[m++] = i;
+        }
+        for (int i = 1; i < m; i++) {
+            int k = order[i], j = i - 1;
+            while (j >= 0 && area[order[j]] < area[k]) { order[j + 1] = order[j]; j--; }
+            order[j + 1] = k;
+        }
+        for (int r = 0; r < m && !found; r++) {
+            int c = order[r];
+            int *tmp = (int *)malloc(sizeof(int) * 2 * (size_t)sizes[c]);
+            double per = svo_arc_length(pts + 2 * off[c], sizes[c], 1);
+            int nv = svo_approx_poly_dp(pts + 2 * off[c], sizes[c], epsilon_ratio * per, 1, tmp);
+            if (nv == 4) { memcpy(corners, tmp, sizeof(int) * 8); found = 1; }
+            free(tmp);
+        }
+        free(area); free(off); free(order);
+    }
+    free(pts);
+    free(sizes);
+    return found;
+}

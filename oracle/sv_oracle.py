@@ -177,3 +177,54 @@ def cells_to_input(cells):
     x = np.empty(cells.shape, np.float32)
     lib().svo_cells_to_input_f32(p, C.c_long(cells.size), x.ctypes.data_as(C.c_void_p))
     return x
+
+
+# ---- A5: host corner search (cv/grid.py:16-71) -------------------------------------------------------
+def find_contours(binary):
+    """-> list of int32 arrays (N,1,2), cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) order."""
+    b, p = _u8(binary)
+    H, W = b.shape
+    pts, sizes, total = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.c_long()
+    n = lib().svo_find_contours(p, H, W, C.c_long(W), C.byref(pts), C.byref(sizes), C.byref(total))
+    out, o = [], 0
+    allp = np.ctypeslib.as_array(pts, shape=(max(total.value, 1), 2)).copy()
+    sz = np.ctypeslib.as_array(sizes, shape=(max(n, 1),)).copy()
+    lib().svo_free(pts)
+    lib().svo_free(sizes)
+    for i in range(n):
+        out.append(allp[o:o + sz[i]].reshape(-1, 1, 2).astype(np.int32))
+        o += sz[i]
+    return out
+
+
+def _pts(c):
+    c = np.ascontiguousarray(np.asarray(c).reshape(-1, 2), np.int32)
+    return c, c.ctypes.data_as(C.c_void_p)
+
+
+def contour_area(contour):
+    c, p = _pts(contour)
+    lib().svo_contour_area.restype = C.c_double
+    return lib().svo_contour_area(p, c.shape[0])
+
+
+def arc_length(contour, closed=True):
+    c, p = _pts(contour)
+    lib().svo_arc_length.restype = C.c_double
+    return lib().svo_arc_length(p, c.shape[0], int(closed))
+
+
+def approx_poly_dp(contour, epsilon, closed=True):
+    c, p = _pts(contour)
+    dst = np.empty((max(c.shape[0], 1), 2), np.int32)
+    n = lib().svo_approx_poly_dp(p, c.shape[0], C.c_double(epsilon), int(closed), dst.ctypes.data_as(C.c_void_p))
+    return dst[:n].reshape(-1, 1, 2).copy()
+
+
+def find_grid_contour(binary, min_area_ratio=0.1, epsilon_ratio=0.02):
+    b, p = _u8(binary)
+    H, W = b.shape
+    corners = np.empty((4, 2), np.int32)
+    found = lib().svo_find_grid_contour(p, H, W, C.c_long(W), C.c_double(min_area_ratio), C.c_double(epsilon_ratio),
+                                        corners.ctypes.data_as(C.c_void_p))
+    return corners if found else None

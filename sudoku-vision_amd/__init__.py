@@ -6,6 +6,7 @@ csrc/libsudokuvision_hip.so (include/sudoku_vision_hip.h).  There is no CPU fall
 that computes needs the HIP library and a GPU, and says so when either is missing.
 """
 from . import _native  # noqa: F401  (does not load the library until first use)
+from . import host  # noqa: F401
 from .runtime import Context, default_context, frames_to_digits  # noqa: F401
 
 __version__ = "0.1.0"

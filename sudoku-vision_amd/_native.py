@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsudokuvision_hip.so")
 
 SV_OK = 0
 ERR_NAMES = {-1: "SV_ERR_BAD_ARG", -2: "SV_ERR_HIP", -3: "SV_ERR_NO_WEIGHTS", -4: "SV_ERR_UNSUPPORTED",
-             -5: "SV_ERR_DEGENERATE"}
+             -5: "SV_ERR_DEGENERATE", -6: "SV_ERR_BUFFER"}
 
 _p, _i, _l, _d, _f, _pd = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_float, C.c_ssize_t
 
@@ -26,6 +26,12 @@ SIGNATURES = {
     "sv_adaptive_threshold_u8": [_p, _p, _i, _i, _i, _i, _d, _i, _p, _p],
     "sv_preprocess_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
     "sv_corners_to_minv": [_p, _i, _i, _f, _p],
+    "sv_find_grid_corners_u8": [_p, _i, _i, _pd, _d, _d, _p],
+    "sv_find_grid_corners_batch_u8": [_p, _i, _i, _i, _pd, _pd, _d, _d, _p, _p, _i],
+    "sv_find_contours_u8": [_p, _i, _i, _pd, _p, _l, _p, _i, _p, _p],
+    "sv_contour_area_i32": [_p, _i, _p],
+    "sv_arc_length_i32": [_p, _i, _i, _p],
+    "sv_approx_poly_dp_i32": [_p, _i, _d, _i, _p, _p],
     "sv_warp_perspective_u8": [_p, _p, _i, _i, _pd, _i, _p, _i, _p, _p],
     "sv_extract_cells_u8": [_p, _p, _i, _i, _pd, _i, _i, _i, _i, _p, _p],
     "sv_warp_cells_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p],

@@ -1,0 +1,371 @@
+// Host-side grid corner search -- the part of the hot path that stays on the CPU (north_star;
+// reference cv/grid.py:16-71).  The reference gets this from cv2 (findContours RETR_EXTERNAL /
+// CHAIN_APPROX_SIMPLE, contourArea, arcLength, approxPolyDP); OpenCV is not a dependency here, so this
+// file implements the same published algorithms: Suzuki-Abe outer-border following on a zero-padded
+// 0/1 image, the shoelace area in double over float vertices, float-sqrt perimeter, and OpenCV's
+// Douglas-Peucker variant for closed curves (farthest-point start search, explicit stack, collinear
+// clean-up).
+//
+// Built for throughput: the raster scan skips runs 8 bytes at a time, small contours are rejected by
+// bounding box before any area/approximation work, and a batch entry point spreads frames over threads.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "sv_internal.h"
+
+namespace {
+
+struct Pt { int x, y; };
+
+const int kDx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+const int kDy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+// Labels written into the work image while following borders (OpenCV's convention).
+constexpr int8_t kTraced = 2;                  // border pixel
+constexpr int8_t kTracedRight = (int8_t)0x82;  // border pixel the border leaves to the right (negative)
+
+struct Contour { size_t first, count; int x0, y0, x1, y1; };  // slice of `points` + bounding box
+
+class BorderScanner {
+  public:
+    BorderScanner(const u8 *bin, int H, int W, ptrdiff_t pitch) : h_(H), w_(W), step_(W + 2), img_((size_t)(W + 2) * (H + 2), 0)
+    {
+        for (int y = 0; y < H; y++) {
+            const u8 *s = bin + (ptrdiff_t)y * pitch;
+            int8_t *d = img_.data() + (size_t)(y + 1) * step_ + 1;
+            for (int x = 0; x < W; x++) d[x] = s[x] != 0;
+        }
+        for (int k = 0; k < 8; k++) delta_[k] = delta_[k + 8] = kDy[k] * step_ + kDx[k];
+    }
+
+    // Raster scan; every outer border that is not enclosed by an already-followed one is traced.
+    void run()
+    {
+        for (int y = 1; y <= h_; y++) {
+            int8_t *row = img_.data() + (size_t)y * step_;
+            int last_marked = 0;  // x of the last labelled pixel seen on this row (0 = padding column)
+            int prev = 0;
+            int x = 1;
+            while (x <= w_) {
+                x = skip_run(row, x, prev);
+                if (x > w_) break;
+                int p = row[x];
+                if (prev == 0 && p == 1 && row[last_marked] <= 0) {
+                    last_marked = x;
+                    follow(row + x, x - 1, y - 1);
+                    p = row[x];
+                }
+                prev = p;
+                if (prev & ~1) last_marked = x;
+                x++;
+            }
+        }
+    }
+
+    std::vector<Pt> points;
+    std::vector<Contour> contours;  // in discovery order (cv2 reports them reversed)
+
+  private:
+    // first x' >= x with row[x'] != prev (or w_+1)
+    int skip_run(const int8_t *row, int x, int prev) const
+    {
+        const uint64_t pat = 0x0101010101010101ull * (uint8_t)prev;
+        while (x + 8 <= w_ + 1) {
+            uint64_t v;
+            memcpy(&v, row + x, 8);
+            if (v != pat) break;
+            x += 8;
+        }
+        while (x <= w_ && row[x] == prev) x++;
+        return x;
+    }
+
+    // Follows one outer border starting at its top-left pixel; keeps the vertices where the direction changes.
+    void follow(int8_t *start, int px, int py)
+    {
+        Contour c{points.size(), 0, px, py, px, py};
+        int s = 4;
+        const int s_stop = 4;
+        int8_t *second;
+        do {
+            s = (s - 1) & 7;
+            second = start + delta_[s];
+        } while (*second == 0 && s != s_stop);
+        if (s == s_stop) {  // isolated pixel
+            *start = kTracedRight;
+            points.push_back({px, py});
+        } else {
+            int8_t *cur = start, *next = nullptr;
+            int prev_dir = s ^ 4;
+            for (;;) {
+                const int s_from = s;
+                while (s < 15) {
+                    next = cur + delta_[++s];
+                    if (*next != 0) break;
+                }
+                s &= 7;
+                if ((unsigned)(s - 1) < (unsigned)s_from) *cur = kTracedRight;
+                else if (*cur == 1) *cur = kTraced;
+                if (s != prev_dir) {
+                    points.push_back({px, py});
+                    c.x0 = std::min(c.x0, px); c.x1 = std::max(c.x1, px);
+                    c.y0 = std::min(c.y0, py); c.y1 = std::max(c.y1, py);
+                    prev_dir = s;
+                }
+                px += kDx[s];
+                py += kDy[s];
+                if (next == start && cur == second) break;
+                cur = next;
+                s = (s + 4) & 7;
+            }
+        }
+        c.count = points.size() - c.first;
+        contours.push_back(c);
+    }
+
+    int h_, w_, step_;
+    std::vector<int8_t> img_;
+    int delta_[16];
+};
+
+double contour_area(const Pt *p, size_t n)
+{
+    if (n == 0) return 0.0;
+    double a = 0.0;
+    float px = (float)p[n - 1].x, py = (float)p[n - 1].y;
+    for (size_t i = 0; i < n; i++) {
+        const float x = (float)p[i].x, y = (float)p[i].y;
+        a += (double)px * y - (double)py * x;
+        px = x;
+        py = y;
+    }
+    return std::fabs(a * 0.5);
+}
+
+double arc_length(const Pt *p, size_t n, bool closed)
+{
+    if (n <= 1) return 0.0;
+    double len = 0.0;
+    const size_t last = closed ? n - 1 : 0;
+    float px = (float)p[last].x, py = (float)p[last].y;
+    for (size_t i = 0; i < n; i++) {
+        const float x = (float)p[i].x, y = (float)p[i].y, dx = x - px, dy = y - py;
+        len += std::sqrt(dx * dx + dy * dy);
+        px = x;
+        py = y;
+    }
+    return len;
+}
+
+// OpenCV's approxPolyDP for integer points.
+std::vector<Pt> approx_poly(const Pt *src, int count, double eps, bool closed_in)
+{
+    std::vector<Pt> dst;
+    if (count == 0) return dst;
+    struct Range { int start, end; };
+    std::vector<Range> stack;
+    auto next = [&](int &pos) { Pt q = src[pos]; if (++pos >= count) pos = 0; return q; };
+    bool closed = closed_in, le_eps = false;
+    int init_iters = 3, pos = 0;
+    Range slice{0, 0}, right{0, 0};
+    Pt start{-1000000, -1000000}, end{0, 0}, pt{0, 0};
+    eps *= eps;
+    if (!closed) {
+        right.start = count;
+        end = src[0];
+        start = src[count - 1];
+        if (start.x != end.x || start.y != end.y) {
+            stack.push_back({0, count - 1});
+        } else {
+            closed = true;
+            init_iters = 1;
+        }
+    }
+    if (closed) {
+        right.start = 0;
+        for (int it = 0; it < init_iters; it++) {  // approximately the two farthest points
+            double max_dist = 0;
+            pos = (pos + right.start) % count;
+            start = next(pos);
+            for (int j = 1; j < count; j++) {
+                pt = next(pos);
+                const double dx = pt.x - start.x, dy = pt.y - start.y, dist = dx * dx + dy * dy;
+                if (dist > max_dist) { max_dist = dist; right.start = j; }
+            }
+            le_eps = max_dist <= eps;
+        }
+        if (!le_eps) {
+            right.end = slice.start = pos % count;
+            slice.end = right.start = (right.start + slice.start) % count;
+            stack.push_back(right);
+            stack.push_back(slice);
+        } else {
+            dst.push_back(start);
+        }
+    }
+    while (!stack.empty()) {
+        slice = stack.back();
+        stack.pop_back();
+        end = src[slice.end];
+        pos = slice.start;
+        start = next(pos);
+        if (pos != slice.end) {
+            const double dx = end.x - start.x, dy = end.y - start.y;
+            double max_dist = 0;
+            while (pos != slice.end) {
+                pt = next(pos);
+                const double dist = std::fabs((pt.y - start.y) * dx - (pt.x - start.x) * dy);
+                if (dist > max_dist) { max_dist = dist; right.start = (pos + count - 1) % count; }
+            }
+            le_eps = max_dist * max_dist <= eps * (dx * dx + dy * dy);
+        } else {
+            le_eps = true;
+            start = src[slice.start];
+        }
+        if (le_eps) {
+            dst.push_back(start);
+        } else {
+            right.end = slice.end;
+            slice.end = right.start;
+            stack.push_back(right);
+            stack.push_back(slice);
+        }
+    }
+    if (!closed) dst.push_back(src[count - 1]);
+
+    // remove vertices on (almost) straight runs
+    const int n0 = (int)dst.size();
+    int n = n0, wpos;
+    auto nextd = [&](int &q) { Pt r = dst[q]; if (++q >= n0) q = 0; return r; };
+    pos = closed_in ? n0 - 1 : 0;
+    start = nextd(pos);
+    wpos = pos;
+    pt = nextd(pos);
+    const int open = closed_in ? 0 : 1;
+    for (int i = open; i < n0 - open && n > 2; i++) {
+        end = nextd(pos);
+        const double dx = end.x - start.x, dy = end.y - start.y;
+        const double dist = std::fabs((pt.x - start.x) * dy - (pt.y - start.y) * dx);
+        const double inner = (double)(pt.x - start.x) * (end.x - pt.x) + (double)(pt.y - start.y) * (end.y - pt.y);
+        if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && inner >= 0) {
+            n--;
+            dst[wpos] = start = end;
+            if (++wpos >= n0) wpos = 0;
+            pt = nextd(pos);
+            i++;
+            continue;
+        }
+        dst[wpos] = start = pt;
+        if (++wpos >= n0) wpos = 0;
+        pt = end;
+    }
+    if (!closed_in) dst[wpos] = pt;
+    dst.resize(n);
+    return dst;
+}
+
+// find_grid_contour, cv/grid.py:37-71
+bool grid_corners(const u8 *bin, int H, int W, ptrdiff_t pitch, double min_area_ratio, double eps_ratio, int *out8)
+{
+    BorderScanner sc(bin, H, W, pitch);
+    sc.run();
+    const double min_area = min_area_ratio * ((double)H * (double)W);
+    struct Cand { double area; size_t idx; };
+    std::vector<Cand> cand;
+    // cv2 lists contours last-found-first; the reference's stable descending sort keeps that order for ties
+    for (size_t k = sc.contours.size(); k-- > 0;) {
+        const Contour &c = sc.contours[k];
+        if ((double)(c.x1 - c.x0) * (double)(c.y1 - c.y0) < min_area) continue;  // area <= bounding box
+        const double a = contour_area(sc.points.data() + c.first, c.count);
+        if (a >= min_area) cand.push_back({a, k});
+    }
+    std::stable_sort(cand.begin(), cand.end(), [](const Cand &a, const Cand &b) { return a.area > b.area; });
+    for (const Cand &cd : cand) {
+        const Contour &c = sc.contours[cd.idx];
+        const Pt *p = sc.points.data() + c.first;
+        const double eps = eps_ratio * arc_length(p, c.count, true);
+        const std::vector<Pt> poly = approx_poly(p, (int)c.count, eps, true);
+        if (poly.size() == 4) {
+            for (int i = 0; i < 4; i++) { out8[2 * i] = poly[i].x; out8[2 * i + 1] = poly[i].y; }
+            return true;
+        }
+    }
+    return false;
+}
+
+}  // namespace
+
+// ---- C ABI -------------------------------------------------------------------------------------------
+extern "C" int sv_find_grid_corners_u8(const uint8_t *binary, int H, int W, ptrdiff_t pitch, double min_area_ratio,
+                                       double epsilon_ratio, int *corners)
+{
+    if (!binary || !corners || H <= 0 || W <= 0 || pitch < W) return sv_fail(SV_ERR_BAD_ARG, "sv_find_grid_corners_u8: bad argument");
+    return grid_corners(binary, H, W, pitch, min_area_ratio, epsilon_ratio, corners) ? 1 : 0;
+}
+
+extern "C" int sv_find_grid_corners_batch_u8(const uint8_t *binary, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
+                                             double min_area_ratio, double epsilon_ratio, int *corners, uint8_t *found, int threads)
+{
+    if (!binary || !corners || !found || n <= 0 || H <= 0 || W <= 0 || pitch < W) return sv_fail(SV_ERR_BAD_ARG, "sv_find_grid_corners_batch_u8: bad argument");
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    auto work = [&](int t) {
+        for (int i = t; i < n; i += threads)
+            found[i] = grid_corners(binary + (ptrdiff_t)i * img_stride, H, W, pitch, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
+    }
+    return SV_OK;
+}
+
+extern "C" int sv_find_contours_u8(const uint8_t *binary, int H, int W, ptrdiff_t pitch, int *points, long cap_points, int *sizes,
+                                   int cap_contours, long *n_points, int *n_contours)
+{
+    if (!binary || !n_points || !n_contours || H <= 0 || W <= 0 || pitch < W) return sv_fail(SV_ERR_BAD_ARG, "sv_find_contours_u8: bad argument");
+    BorderScanner sc(binary, H, W, pitch);
+    sc.run();
+    *n_points = (long)sc.points.size();
+    *n_contours = (int)sc.contours.size();
+    if ((long)sc.points.size() > cap_points || (int)sc.contours.size() > cap_contours || !points || !sizes)
+        return sv_fail(SV_ERR_BUFFER, "sv_find_contours_u8: need room for %ld points in %d contours", *n_points, *n_contours);
+    long w = 0;
+    int ci = 0;
+    for (size_t k = sc.contours.size(); k-- > 0; ci++) {  // cv2 order: last found first
+        const Contour &c = sc.contours[k];
+        sizes[ci] = (int)c.count;
+        for (size_t i = 0; i < c.count; i++) { points[2 * w] = sc.points[c.first + i].x; points[2 * w + 1] = sc.points[c.first + i].y; w++; }
+    }
+    return SV_OK;
+}
+
+extern "C" int sv_contour_area_i32(const int *xy, int n, double *area)
+{
+    if ((!xy && n > 0) || n < 0 || !area) return sv_fail(SV_ERR_BAD_ARG, "sv_contour_area_i32: bad argument");
+    *area = contour_area(reinterpret_cast<const Pt *>(xy), (size_t)n);
+    return SV_OK;
+}
+
+extern "C" int sv_arc_length_i32(const int *xy, int n, int closed, double *length)
+{
+    if ((!xy && n > 0) || n < 0 || !length) return sv_fail(SV_ERR_BAD_ARG, "sv_arc_length_i32: bad argument");
+    *length = arc_length(reinterpret_cast<const Pt *>(xy), (size_t)n, closed != 0);
+    return SV_OK;
+}
+
+extern "C" int sv_approx_poly_dp_i32(const int *xy, int n, double epsilon, int closed, int *out, int *n_out)
+{
+    if ((!xy && n > 0) || n < 0 || !out || !n_out || epsilon < 0) return sv_fail(SV_ERR_BAD_ARG, "sv_approx_poly_dp_i32: bad argument");
+    const std::vector<Pt> r = approx_poly(reinterpret_cast<const Pt *>(xy), n, epsilon, closed != 0);
+    *n_out = (int)r.size();
+    for (size_t i = 0; i < r.size(); i++) { out[2 * i] = r[i].x; out[2 * i + 1] = r[i].y; }
+    return SV_OK;
+}

@@ -12,22 +12,27 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from _bootstrap import package  # noqa: E402
 sys.path.pop(0)
-_rt = package().runtime
+_pkg = package()
+_rt = _pkg.runtime
+_host = _pkg.host
 
 
 def find_contours(binary):
-    """External contours of a binary image (reference cv/grid.py:16-21)."""
-    raise NotImplementedError("host contour search lands with scope row N2")
+    """Find all (external) contours in a binary image (reference cv/grid.py:16-21)."""
+    return _host.find_contours(binary)
 
 
 def approximate_polygon(contour, epsilon_ratio: float = 0.02):
-    """Douglas-Peucker approximation at epsilon_ratio * perimeter (reference cv/grid.py:24-34)."""
-    raise NotImplementedError("host contour search lands with scope row N2")
+    """Approximate contour with a polygon at epsilon_ratio * perimeter (reference cv/grid.py:24-34)."""
+    perimeter = _host.arc_length(contour, closed=True)
+    return _host.approx_poly_dp(contour, epsilon_ratio * perimeter, closed=True)
 
 
 def find_grid_contour(binary, min_area_ratio: float = 0.1):
-    """Largest quadrilateral contour, or None (reference cv/grid.py:37-71)."""
-    raise NotImplementedError("host contour search lands with scope row N2")
+    """The sudoku grid contour = largest quadrilateral; 4 corner points or None (reference cv/grid.py:37-71)."""
+    if isinstance(binary, torch.Tensor):
+        binary = binary.cpu().numpy()
+    return _host.find_grid_corners(binary, min_area_ratio=min_area_ratio, epsilon_ratio=0.02)
 
 
 def order_points(pts):

@@ -1,0 +1,90 @@
+"""Host (CPU) half of the hot path: the contour-based grid corner search of cv/grid.py:16-71, implemented
+in C++ inside libsudokuvision_hip.so (csrc/host_contours.cpp).  Needs no GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _native
+
+
+def _bin(binary):
+    b = np.asarray(binary)
+    if b.dtype != np.uint8 or b.ndim != 2:
+        raise TypeError("expected a 2-D uint8 binary image")
+    return np.ascontiguousarray(b)
+
+
+def find_contours(binary):
+    """-> list of int32 arrays of shape (N,1,2), in cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) order."""
+    b = _bin(binary)
+    H, W = b.shape
+    lib = _native.lib()
+    npts, ncont = C.c_long(), C.c_int()
+    rc = lib.sv_find_contours_u8(b.ctypes.data_as(C.c_void_p), H, W, W, None, 0, None, 0, C.byref(npts), C.byref(ncont))
+    if rc not in (0, -6):
+        _native.check(rc, "sv_find_contours_u8")
+    pts = np.empty((max(npts.value, 1), 2), np.int32)
+    sizes = np.empty(max(ncont.value, 1), np.int32)
+    _native.check(lib.sv_find_contours_u8(b.ctypes.data_as(C.c_void_p), H, W, W, pts.ctypes.data_as(C.c_void_p), npts.value,
+                                          sizes.ctypes.data_as(C.c_void_p), ncont.value, C.byref(npts), C.byref(ncont)), "sv_find_contours_u8")
+    out, o = [], 0
+    for i in range(ncont.value):
+        out.append(pts[o:o + sizes[i]].reshape(-1, 1, 2).copy())
+        o += sizes[i]
+    return out
+
+
+def _pts(contour):
+    return np.ascontiguousarray(np.asarray(contour).reshape(-1, 2), np.int32)
+
+
+def contour_area(contour) -> float:
+    c = _pts(contour)
+    v = C.c_double()
+    _native.check(_native.lib().sv_contour_area_i32(c.ctypes.data_as(C.c_void_p), c.shape[0], C.byref(v)), "sv_contour_area_i32")
+    return v.value
+
+
+def arc_length(contour, closed=True) -> float:
+    c = _pts(contour)
+    v = C.c_double()
+    _native.check(_native.lib().sv_arc_length_i32(c.ctypes.data_as(C.c_void_p), c.shape[0], int(bool(closed)), C.byref(v)), "sv_arc_length_i32")
+    return v.value
+
+
+def approx_poly_dp(contour, epsilon, closed=True):
+    c = _pts(contour)
+    out = np.empty((max(c.shape[0], 1), 2), np.int32)
+    n = C.c_int()
+    _native.check(_native.lib().sv_approx_poly_dp_i32(c.ctypes.data_as(C.c_void_p), c.shape[0], float(epsilon), int(bool(closed)),
+                                                      out.ctypes.data_as(C.c_void_p), C.byref(n)), "sv_approx_poly_dp_i32")
+    return out[:n.value].reshape(-1, 1, 2).copy()
+
+
+def find_grid_corners(binary, min_area_ratio=0.1, epsilon_ratio=0.02):
+    """-> int32 (4,2) or None."""
+    b = _bin(binary)
+    H, W = b.shape
+    corners = np.empty((4, 2), np.int32)
+    rc = _native.lib().sv_find_grid_corners_u8(b.ctypes.data_as(C.c_void_p), H, W, W, float(min_area_ratio), float(epsilon_ratio),
+                                               corners.ctypes.data_as(C.c_void_p))
+    if rc < 0:
+        _native.check(rc, "sv_find_grid_corners_u8")
+    return corners if rc == 1 else None
+
+
+def find_grid_corners_batch(binaries, min_area_ratio=0.1, epsilon_ratio=0.02, threads=None):
+    """binaries uint8 [n,H,W] (host) -> (corners int32 [n,4,2], found bool [n])."""
+    b = np.asarray(binaries)
+    if b.dtype != np.uint8 or b.ndim != 3:
+        raise TypeError("expected uint8 [n,H,W]")
+    b = np.ascontiguousarray(b)
+    n, H, W = b.shape
+    corners = np.zeros((n, 4, 2), np.int32)
+    found = np.zeros(n, np.uint8)
+    threads = threads or min(n, os.cpu_count() or 1)
+    _native.check(_native.lib().sv_find_grid_corners_batch_u8(b.ctypes.data_as(C.c_void_p), n, H, W, W, H * W, float(min_area_ratio),
+                                                              float(epsilon_ratio), corners.ctypes.data_as(C.c_void_p),
+                                                              found.ctypes.data_as(C.c_void_p), int(threads)), "sv_find_grid_corners_batch_u8")
+    return corners, found.astype(bool)

@@ -1,0 +1,139 @@
+"""CPU: the host corner search (cv/grid.py:16-71).  Product = csrc/host_contours.cpp through the C ABI;
+checker = oracle/sv_oracle.c; independent cross-checks = scipy.ndimage.label and known cv2 conventions."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+import sv_oracle as o
+
+
+@pytest.fixture(scope="module")
+def host():
+    import sudoku_vision_amd as sva
+    sva._native.lib()
+    return sva.host
+
+
+def _blobs(seed, h, w, thr=0.55):
+    rs = np.random.RandomState(seed)
+    return ((ndimage.gaussian_filter(rs.uniform(size=(h, w)), 2.5) > np.quantile(ndimage.gaussian_filter(rs.uniform(size=(h, w)), 2.5), thr)) * 255).astype(np.uint8)
+
+
+def test_oracle_known_conventions():
+    img = np.zeros((8, 8), np.uint8)
+    img[2:6, 2:6] = 255
+    # cv2 lists a filled square counter-clockwise from its top-left pixel: TL, BL, BR, TR
+    assert [c.reshape(-1, 2).tolist() for c in o.find_contours(img)] == [[[2, 2], [2, 5], [5, 5], [5, 2]]]
+    img[3:5, 3:5] = 0                       # a hole is not an external contour
+    assert len(o.find_contours(img)) == 1
+    img[:] = 0
+    img[0, 0] = img[2, 3] = img[7, 7] = 255
+    got = [c.reshape(-1, 2).tolist() for c in o.find_contours(img)]
+    assert got == [[[7, 7]], [[3, 2]], [[0, 0]]]          # last found first; single pixels; image-border pixels kept
+    assert o.find_contours(np.zeros((5, 5), np.uint8)) == []
+    full = o.find_contours(np.full((4, 6), 255, np.uint8))
+    assert [c.reshape(-1, 2).tolist() for c in full] == [[[0, 0], [0, 3], [5, 3], [5, 0]]]
+
+
+def test_oracle_area_length_approx():
+    sq = np.array([[2, 2], [2, 5], [5, 5], [5, 2]])
+    assert o.contour_area(sq) == 9.0 and o.arc_length(sq) == 12.0 and o.arc_length(sq, closed=False) == 9.0
+    assert o.contour_area(np.zeros((0, 2))) == 0.0
+    # a noisy rectangle collapses to its 4 corners
+    t = np.arange(0, 100)
+    top = np.stack([t, (t % 2)], 1)
+    right = np.stack([100 + (t % 2), t], 1)
+    bottom = np.stack([100 - t, 100 - (t % 2)], 1)
+    left = np.stack([(t % 2), 100 - t], 1)
+    poly = np.concatenate([top, right, bottom, left])
+    ap = o.approx_poly_dp(poly, 0.02 * o.arc_length(poly)).reshape(-1, 2)
+    assert len(ap) == 4
+    want = np.array([[0, 0], [0, 100], [100, 0], [100, 100]])
+    assert np.abs(ap[np.lexsort((ap[:, 1], ap[:, 0]))] - want).max() <= 1
+    assert len(o.approx_poly_dp(poly, 0.0)) > 100          # epsilon 0 keeps the zig-zag
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_external_contours_vs_labels(seed):
+    """Every external contour belongs to exactly one 8-connected component and starts at that component's
+    first pixel in raster order; components enclosed by another component's hole are not reported."""
+    img = _blobs(seed, 90, 120)
+    lab, n = ndimage.label(img > 0, structure=np.ones((3, 3)))
+    cs = o.find_contours(img)
+    seen = set()
+    for c in cs:
+        p = c.reshape(-1, 2)
+        ids = {lab[y, x] for x, y in p}
+        assert len(ids) == 1 and 0 not in ids
+        cid = ids.pop()
+        assert cid not in seen
+        seen.add(cid)
+        ys, xs = np.nonzero(lab == cid)
+        assert (p[0] == [xs[ys == ys.min()].min(), ys.min()]).all()
+    # components not reported must be enclosed: filling the holes of the reported ones covers them
+    filled = ndimage.binary_fill_holes(np.isin(lab, list(seen)), structure=np.ones((3, 3)))  # holes w.r.t. 4-connected background
+    missing = set(range(1, n + 1)) - seen
+    for cid in missing:
+        assert filled[lab == cid].all()
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+def test_product_equals_oracle_on_blobs(host, seed):
+    img = _blobs(seed, 150, 200, thr=0.45 + 0.05 * (seed % 3))
+    a, b = host.find_contours(img), o.find_contours(img)
+    assert len(a) == len(b) and all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
+    for c in a[:50]:
+        assert host.contour_area(c) == o.contour_area(c)
+        assert host.arc_length(c) == o.arc_length(c)
+        for er in (0.0, 0.005, 0.02, 0.1):
+            eps = er * o.arc_length(c)
+            assert (host.approx_poly_dp(c, eps) == o.approx_poly_dp(c, eps)).all()
+            assert (host.approx_poly_dp(c, eps, closed=False) == o.approx_poly_dp(c, eps, closed=False)).all()
+    for mar in (0.1, 0.01, 0.0):
+        g, go = host.find_grid_corners(img, mar), o.find_grid_contour(img, mar)
+        assert (g is None) == (go is None) and (g is None or (g == go).all())
+
+
+def test_synthetic_frames_corners(host):
+    from sudoku_vision_amd.synth import synth_frames
+    frames, corners, _ = synth_frames(3, 540, 960, seed=12)
+    bins = np.stack([o.preprocess_for_grid_detection(f) for f in frames.numpy()])
+    got, found = host.find_grid_corners_batch(bins, threads=2)
+    assert found.all()
+    for i in range(3):
+        assert (got[i] == o.find_grid_contour(bins[i])).all()
+        assert got[i].dtype == np.int32 and got[i].shape == (4, 2)
+        ordered = o.order_points(got[i].astype(np.float32))
+        assert np.abs(ordered - corners[i]).max() <= 6          # outer edge of the border line, ~half a line width out
+    assert host.find_grid_corners(np.zeros((64, 64), np.uint8)) is None        # "not found" is None, never an exception
+    noise = (np.random.RandomState(0).uniform(size=(128, 128)) > 0.7).astype(np.uint8) * 255
+    assert host.find_grid_corners(noise) is None and o.find_grid_contour(noise) is None
+
+
+def test_reference_named_functions(host):
+    """find_contours / approximate_polygon / find_grid_contour as cv/grid.py exposes them."""
+    from sudoku_vision_amd.cv.grid import find_contours, approximate_polygon, find_grid_contour, order_points
+    img = np.zeros((200, 300), np.uint8)
+    img[20:180, 40:260] = 255
+    img[30:170, 50:250] = 0
+    cs = find_contours(img)
+    assert len(cs) == 1 and cs[0].dtype == np.int32 and cs[0].shape[1:] == (1, 2)
+    ap = approximate_polygon(cs[0])
+    assert ap.shape == (4, 1, 2)
+    g = find_grid_contour(img)
+    assert g.shape == (4, 2) and order_points(g).tolist() == [[40, 20], [259, 20], [259, 179], [40, 179]]
+    assert find_grid_contour(img, min_area_ratio=0.9) is None
+
+
+def test_buffer_protocol_and_bad_args(host):
+    import ctypes as C
+    import sudoku_vision_amd as sva
+    lib = sva._native.lib()
+    img = np.zeros((16, 16), np.uint8)
+    img[4:8, 4:8] = 255
+    n, m = C.c_long(), C.c_int()
+    assert lib.sv_find_contours_u8(img.ctypes.data_as(C.c_void_p), 16, 16, 16, None, 0, None, 0, C.byref(n), C.byref(m)) == -6
+    assert (n.value, m.value) == (4, 1)
+    assert lib.sv_find_grid_corners_u8(None, 16, 16, 16, 0.1, 0.02, None) == -1
+    with pytest.raises(TypeError):
+        host.find_grid_corners(np.zeros((4, 4), np.float32))

@@ -15,8 +15,11 @@
  * test or fixture for cv2 outputs (its tests assert only len(cells)==81), and cv2 cannot be run
  * here.  The integer stages (gray, 5x5 blur, warp, resize) follow OpenCV's bit-exact fixed-point
  * definitions; the one float stage (the 11x11 Gaussian inside adaptiveThreshold) follows the
- * scalar, non-FMA operation order of OpenCV's FilterEngine -- an AVX2/FMA OpenCV build may differ
- * from it on pixels whose float mean lies within ~1e-5 of a .5 tie.
+ * operation order of OpenCV's FilterEngine with FUSED multiply-adds, which is what its vector code
+ * executes wherever opencv-python runs today (x86 wheels dispatch filter.simd.hpp to AVX2+FMA3:
+ * RowVec_32f / SymmColumnVec_32f use _mm256_fmadd_ps / v_muladd; aarch64 NEON v_muladd is fused too).
+ * An SSE-only x86 build rounds the multiply and the add separately and may differ from this file on
+ * pixels whose float mean lies within ~1e-5 of a .5 tie.
  *
  * Plain C99, no dependencies beyond libm.  Build: make -C oracle
  */
@@ -125,15 +128,15 @@ int svo_gaussian_kernel_f32(int n, float *out)
  * A3  threshold()  -- reference cv/preprocess.py:32-54 (BINARY_INV) and pipeline/run.py:91-93
  *     (BINARY): cv2.adaptiveThreshold(img,255,GAUSSIAN_C,type,block,c).
  *     src -> f32; separable Gaussian (taps above), border REPLICATE; row pass then column pass in
- *     FilterEngine's scalar order, every multiply and add rounded to f32 separately (no FMA);
+ *     FilterEngine's order with fused multiply-adds (see the file header);
  *     mean = round-half-even -> u8 (saturated); out = LUT[src - mean + 255].
  *     type: 0 = THRESH_BINARY, 1 = THRESH_BINARY_INV.
  * ---------------------------------------------------------------------------------------------- */
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-/* one IEEE rounding per operation: this file is built with -ffp-contract=off (oracle/Makefile) */
-static inline float fmul(float a, float b) { return a * b; }
-static inline float fadd(float a, float b) { return a + b; }
+/* Fused multiply-add exactly where OpenCV's vector filter code has one; everything else rounds per
+ * operation (the file is built with -ffp-contract=off, oracle/Makefile). */
+static inline float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 int svo_adaptive_mean_u8(const u8 *src, int H, int W, int block, u8 *mean)
 {
@@ -145,26 +148,25 @@ int svo_adaptive_mean_u8(const u8 *src, int H, int W, int block, u8 *mean)
         const u8 *s = src + (long)y * W;
         for (int x = 0; x < W; x++) {
             float acc;
-            if (block <= 5) { /* SymmRowSmallFilter: centre, then symmetric pairs */
-                acc = fmul((float)s[x], k[r]);
+            if (block <= 5) { /* SymmRowSmallVec_32f: centre * k0, then fma((left+right), k_j, acc) */
+                acc = (float)s[x] * k[r];
                 for (int j = 1; j <= r; j++) {
-                    float pr = fadd((float)s[clampi(x - j, 0, W - 1)], (float)s[clampi(x + j, 0, W - 1)]);
-                    acc = fadd(acc, fmul(pr, k[r + j]));
+                    float pr = (float)s[clampi(x - j, 0, W - 1)] + (float)s[clampi(x + j, 0, W - 1)];
+                    acc = ffma(pr, k[r + j], acc);
                 }
-            } else {          /* RowFilter: taps left to right */
-                acc = fmul(k[0], (float)s[clampi(x - r, 0, W - 1)]);
-                for (int j = 1; j < block; j++)
-                    acc = fadd(acc, fmul(k[j], (float)s[clampi(x + j - r, 0, W - 1)]));
+            } else {          /* RowVec_32f: s = x0*k0; s = fma(x_j, k_j, s), taps left to right */
+                acc = k[0] * (float)s[clampi(x - r, 0, W - 1)];
+                for (int j = 1; j < block; j++) acc = ffma((float)s[clampi(x + j - r, 0, W - 1)], k[j], acc);
             }
             rows[(long)y * W + x] = acc;
         }
     }
     for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) { /* SymmColumnFilter: centre (+delta 0), then pairs outward */
-            float acc = fadd(fmul(k[r], rows[(long)y * W + x]), 0.f);
+        for (int x = 0; x < W; x++) { /* SymmColumnVec_32f: fma(centre, k0, delta=0), then fma(below+above, k_j, acc) */
+            float acc = ffma(rows[(long)y * W + x], k[r], 0.f);
             for (int j = 1; j <= r; j++) {
-                float pr = fadd(rows[(long)clampi(y + j, 0, H - 1) * W + x], rows[(long)clampi(y - j, 0, H - 1) * W + x]);
-                acc = fadd(acc, fmul(k[r + j], pr));
+                float pr = rows[(long)clampi(y + j, 0, H - 1) * W + x] + rows[(long)clampi(y - j, 0, H - 1) * W + x];
+                acc = ffma(pr, k[r + j], acc);
             }
             long m = lrintf(acc); /* round half to even (default FP environment) */
             mean[(long)y * W + x] = (u8)(m < 0 ? 0 : (m > 255 ? 255 : m));
@@ -299,10 +301,10 @@ int svo_corners_to_minv(const float corners[8], int out_size, float inset_ratio,
     for (int i = 0; i < 4; i++) {
         float dx = cx - o[2 * i], dy = cy - o[2 * i + 1];
         /* np.linalg.norm on float32[2]: sqrt(dx*dx + dy*dy) in float32 */
-        float dist = sqrtf(fadd(fmul(dx, dx), fmul(dy, dy)));
-        float amt = fmul(dist, inset_ratio);
-        in[2 * i] = fadd(o[2 * i], fmul(dx / dist, amt));
-        in[2 * i + 1] = fadd(o[2 * i + 1], fmul(dy / dist, amt));
+        float dist = sqrtf(dx * dx + dy * dy);
+        float amt = dist * inset_ratio;
+        in[2 * i] = o[2 * i] + (dx / dist) * amt;
+        in[2 * i + 1] = o[2 * i + 1] + (dy / dist) * amt;
     }
     const float S = (float)(out_size - 1);
     const float dst[8] = {0, 0, S, 0, S, S, 0, S};

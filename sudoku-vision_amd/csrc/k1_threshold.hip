@@ -7,11 +7,12 @@
 //   k_gray / k_blur / k_adaptive_threshold : the three stages as stand-alone calls (grayscale(),
 //                        blur(), threshold() of preprocess.py) for drop-in use; direct form.
 //
-// The f32 Gaussian rounds after every multiply and every add, in the order OpenCV's scalar
-// FilterEngine uses (row: taps left to right; column: centre, then symmetric pairs outward), so the
-// output is bit-identical to the CPU oracle.
+// The f32 Gaussian follows OpenCV's FilterEngine order with the fused multiply-adds its AVX2/FMA3 and
+// NEON vector code executes (row: s = x0*k0, then fma(x_j, k_j, s) left to right; column: centre*k0,
+// then fma(below + above, k_j, s) outward), so the output is bit-identical to the CPU oracle.
 #include "sv_device.h"
 #include "sv_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void k_preprocess_any(const u8 *__restrict__ b
         const int br = i / TW, x = i - br * TW;
         float acc = __fmul_rn(taps.k[0], bl[br][x]);
 #pragma unroll
-        for (int j = 1; j < 11; j++) acc = __fadd_rn(acc, __fmul_rn(taps.k[j], bl[br][x + j]));
+        for (int j = 1; j < 11; j++) acc = __builtin_fmaf(bl[br][x + j], taps.k[j], acc);
         rw[br][x] = acc;
     }
     __syncthreads();
@@ -78,9 +79,9 @@ __global__ __launch_bounds__(256) void k_preprocess_any(const u8 *__restrict__ b
     for (int i = tid; i < TH * TW; i += 256) {
         const int y = i / TW, x = i - y * TW;
         if (x0 + x >= W || y0 + y >= H) continue;
-        float acc = __fadd_rn(__fmul_rn(taps.k[5], rw[y + 5][x]), 0.f);
+        float acc = __fmul_rn(taps.k[5], rw[y + 5][x]);
 #pragma unroll
-        for (int j = 1; j <= 5; j++) acc = __fadd_rn(acc, __fmul_rn(taps.k[5 + j], __fadd_rn(rw[y + 5 + j][x], rw[y + 5 - j][x])));
+        for (int j = 1; j <= 5; j++) acc = __builtin_fmaf(__fadd_rn(rw[y + 5 + j][x], rw[y + 5 - j][x]), taps.k[5 + j], acc);
         const int mean = sv_clamp(__float2int_rn(acc), 0, 255);
         const int src = (int)bl[y + 5][x + 5];
         dst[(ptrdiff_t)(y0 + y) * W + (x0 + x)] = (src - mean <= -2) ? 255 : 0;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(NT) void k_preprocess_tiled(const u8 *__restrict__ 
         for (int c = 0; c < 4; c++) {
             float acc = __fmul_rn(taps.k[0], v[c]);
 #pragma unroll
-            for (int j = 1; j < 11; j++) acc = __fadd_rn(acc, __fmul_rn(taps.k[j], v[c + j]));
+            for (int j = 1; j < 11; j++) acc = __builtin_fmaf(v[c + j], taps.k[j], acc);
             o[c] = acc;
         }
         rw4[it] = o;
@@ -261,10 +262,192 @@ __global__ __launch_bounds__(NT) void k_preprocess_tiled(const u8 *__restrict__ 
                     // (FilterEngine adds delta = +0.f here; every operand is >= +0, so the sum is unchanged)
                     float acc = __fmul_rn(taps.k[5], win[r + 5][c]);
 #pragma unroll
-                    for (int j = 1; j <= 5; j++) acc = __fadd_rn(acc, __fmul_rn(taps.k[5 + j], __fadd_rn(win[r + 5 + j][c], win[r + 5 - j][c])));
+                    for (int j = 1; j <= 5; j++) acc = __builtin_fmaf(__fadd_rn(win[r + 5 + j][c], win[r + 5 - j][c]), taps.k[5 + j], acc);
                     const int mean = sv_clamp(__float2int_rn(acc), 0, 255);
                     const int sv = (int)((srcw >> (8 * c)) & 255);
                     o |= (sv - mean <= -2 ? 255u : 0u) << (8 * c);
+                }
+                const int gx = x0 + 4 * k;
+                u8 *d = dst + (ptrdiff_t)(y0 + y) * W + gx;
+                if (aligned4 && gx + 3 < W) *(u32 *)d = o;
+                else
+                    for (int c = 0; c < 4; c++)
+                        if (gx + c < W) d[c] = (u8)(o >> (8 * c));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The float-pipe variant of the tiled kernel (the one the dispatcher uses).  gfx950 issues f32
+// add/mul/fma at full rate but VOP3 integer and conversion instructions at about half of it
+// (profiles/r01_ubench_valu_rates.txt), and every integer stage here is exact in f32 (all values
+// < 2^24), so after the byte -> float conversion everything runs on the f32 pipe:
+//   AB  gray = floor(fma chain with coefficients/2^15 + 0.5)            (== (.. + 2^14) >> 15)
+//       horizontal 1-4-6-4-1 in the same pass: a wave owns whole rows (3 rows x 20 groups = 60 lanes), the
+//       two neighbouring pixels on either side come from the adjacent lanes by DPP wave shifts
+//   C   vertical 1-4-6-4-1, floor(fma(v, 1/256, 0.5))                   (== (v + 128) >> 8)
+//   D/E as in the integer variant; the compare is  rint(mean) - src >= 2.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_prev(float v)   // value held by lane-1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v)   // value held by lane+1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float gray_f32(float b, float g, float r)
+{
+    return floorf(__builtin_fmaf(b, 3735.f / 32768.f, __builtin_fmaf(g, 19235.f / 32768.f, __builtin_fmaf(r, 9798.f / 32768.f, 0.5f))));
+}
+__device__ __forceinline__ float blur5(float a, float b, float c, float d, float e)   // a + 4b + 6c + 4d + e, exact
+{
+    return __builtin_fmaf(6.f, c, __builtin_fmaf(4.f, b + d, a + e));
+}
+
+template <int TW, int TH, int NT, int RC, int RE>
+__global__ __launch_bounds__(NT) void k_preprocess_f32(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch,
+                                                       ptrdiff_t img_stride, u8 *__restrict__ out, Taps11 taps, int aligned4)
+{
+    constexpr int GW = TW + 16, GH = TH + 14, BH = TH + 10, NG = GW / 4, NK = TW / 4, NWAVE = NT / 64;
+    constexpr int ROWS_PER_WAVE = 64 / NG;                    // 3 rows of 20 groups, 4 lanes idle
+    static_assert(BH * TW <= GH * GW, "rw must fit in hf");
+    __shared__ __attribute__((aligned(16))) float smem[GH * GW + BH * GW];
+    f32x4_t *hf4 = (f32x4_t *)smem;                           // [GH][NG]  horizontal pass (x 16 scale kept)
+    f32x4_t *rw4 = (f32x4_t *)smem;                           // [BH][NK]  f32 row pass (after hf is dead)
+    f32x4_t *bf4 = (f32x4_t *)(smem + GH * GW);               // [BH][NG]  blurred image as f32
+    float *bf = smem + GH * GW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const u8 *img = bgr + (ptrdiff_t)blockIdx.z * img_stride;
+    u8 *dst = out + (ptrdiff_t)blockIdx.z * H * W;
+
+    // ---- AB: gray + horizontal pass, whole rows per wave
+    {
+        const int rl = lane / NG, g = lane - rl * NG;
+        const int gx = x0 - 8 + 4 * g;
+        const bool fast = aligned4 && gx >= 0 && gx + 3 < W;
+        for (int base = 0; base < GH; base += NWAVE * ROWS_PER_WAVE) {
+            const int ly = base + wave * ROWS_PER_WAVE + rl;
+            const int lyc = ly < GH ? ly : GH - 1;
+            const int sy = sv_reflect101(sv_clamp(y0 - 7 + lyc, -2, H + 1), H);
+            const u8 *row = img + (ptrdiff_t)sy * pitch;
+            float p0, p1, p2, p3;
+            if (fast) {
+                const u32x3 d = *(const u32x3 *)(row + 3 * gx);
+                p0 = gray_f32((float)(d.a & 255), (float)((d.a >> 8) & 255), (float)((d.a >> 16) & 255));
+                p1 = gray_f32((float)(d.a >> 24), (float)(d.b & 255), (float)((d.b >> 8) & 255));
+                p2 = gray_f32((float)((d.b >> 16) & 255), (float)(d.b >> 24), (float)(d.c & 255));
+                p3 = gray_f32((float)((d.c >> 8) & 255), (float)((d.c >> 16) & 255), (float)(d.c >> 24));
+            } else {
+                float q[4];
+                for (int i = 0; i < 4; i++) {
+                    const int sx = sv_reflect101(sv_clamp(gx + i, -2, W + 1), W);
+                    const u8 *p = row + (ptrdiff_t)sx * 3;
+                    q[i] = gray_f32((float)p[0], (float)p[1], (float)p[2]);
+                }
+                p0 = q[0]; p1 = q[1]; p2 = q[2]; p3 = q[3];
+            }
+            // neighbours across the group boundary (garbage only in columns 0,1 and GW-2,GW-1, which nobody reads)
+            const float l2 = lane_prev(p2), l3 = lane_prev(p3), r0 = lane_next(p0), r1 = lane_next(p1);
+            f32x4_t h;
+            h[0] = blur5(l2, l3, p0, p1, p2);
+            h[1] = blur5(l3, p0, p1, p2, p3);
+            h[2] = blur5(p0, p1, p2, p3, r0);
+            h[3] = blur5(p1, p2, p3, r0, r1);
+            if (lane < ROWS_PER_WAVE * NG && ly < GH) hf4[ly * NG + g] = h;
+        }
+    }
+    __syncthreads();
+
+    // ---- C: vertical pass, sliding window down the column
+    {
+        constexpr int NCH = (BH + RC - 1) / RC;
+        for (int it = tid; it < NCH * NG; it += NT) {
+            const int ch = it / NG, g = it - ch * NG;
+            const int br0 = ch * RC;
+            f32x4_t win[RC + 4];
+#pragma unroll
+            for (int r = 0; r < RC + 4; r++) win[r] = hf4[(br0 + r < GH ? br0 + r : GH - 1) * NG + g];
+#pragma unroll
+            for (int r = 0; r < RC; r++) {
+                if (br0 + r < BH) {
+                    f32x4_t o;
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        o[c] = floorf(__builtin_fmaf(blur5(win[r][c], win[r + 1][c], win[r + 2][c], win[r + 3][c], win[r + 4][c]), 1.f / 256.f, 0.5f));
+                    bf4[(br0 + r) * NG + g] = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- edge tiles: blurred halo outside the image = REPLICATE of the blurred image
+    if (x0 < 5 || x0 + TW + 5 > W || y0 < 5 || y0 + TH + 5 > H) {
+        for (int it = tid; it < BH * GW; it += NT) {
+            const int br = it / GW, c = it - br * GW;
+            const int q = x0 - 8 + c;
+            if (q < 0 || q >= W) {
+                const int sc = sv_clamp(q, 0, W - 1) - (x0 - 8);
+                if (sc >= 0 && sc < GW) bf[br * GW + c] = bf[br * GW + sc];
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < BH * NG; it += NT) {
+            const int br = it / NG, g = it - br * NG;
+            const int r = y0 - 5 + br;
+            if (r < 0 || r >= H) {
+                const int sr = sv_clamp(r, 0, H - 1) - (y0 - 5);
+                if (sr >= 0 && sr < BH) bf4[it] = bf4[sr * NG + g];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- D: f32 row pass.  Outputs x = 4k..4k+3 read blurred columns 4k+3 .. 4k+16 (array index space)
+    for (int it = tid; it < BH * NK; it += NT) {
+        const int br = it / NK, k = it - br * NK;
+        const f32x4_t *src = bf4 + br * NG + k;
+        const f32x4_t a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4];
+        const float v[14] = {a0[3], a1[0], a1[1], a1[2], a1[3], a2[0], a2[1], a2[2], a2[3], a3[0], a3[1], a3[2], a3[3], a4[0]};
+        f32x4_t o;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float acc = __fmul_rn(taps.k[0], v[c]);
+#pragma unroll
+            for (int j = 1; j < 11; j++) acc = __builtin_fmaf(v[c + j], taps.k[j], acc);
+            o[c] = acc;
+        }
+        rw4[it] = o;       // rw aliases hf: hf's last reader (stage C) is two barriers behind
+    }
+    __syncthreads();
+
+    // ---- E: f32 column pass, round, compare, store
+    {
+        constexpr int NCH = (TH + RE - 1) / RE;
+        for (int it = tid; it < NCH * NK; it += NT) {
+            const int ch = it / NK, k = it - ch * NK;
+            const int yb = ch * RE;
+            f32x4_t win[RE + 10];
+#pragma unroll
+            for (int r = 0; r < RE + 10; r++) win[r] = rw4[(yb + r < BH ? yb + r : BH - 1) * NK + k];
+#pragma unroll
+            for (int r = 0; r < RE; r++) {
+                const int y = yb + r;
+                if (y >= TH || y0 + y >= H) continue;
+                const f32x4_t srcv = bf4[(y + 5) * NG + k + 2];
+                u32 o = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    // (FilterEngine adds delta = +0.f first; every operand is >= +0, so the sum is unchanged)
+                    float acc = __fmul_rn(taps.k[5], win[r + 5][c]);
+#pragma unroll
+                    for (int j = 1; j <= 5; j++) acc = __builtin_fmaf(__fadd_rn(win[r + 5 + j][c], win[r + 5 - j][c]), taps.k[5 + j], acc);
+                    // mean = rint(acc) lies in [0,255] without clamping (acc <= 255*(1+1e-8)); src - mean <= -2
+                    o |= (__fsub_rn(rintf(acc), srcv[c]) >= 2.f ? 255u : 0u) << (8 * c);
                 }
                 const int gx = x0 + 4 * k;
                 u8 *d = dst + (ptrdiff_t)(y0 + y) * W + gx;
@@ -314,11 +497,11 @@ __device__ __forceinline__ float row_value(const u8 *row, int x, int W, const FT
         acc = __fmul_rn((float)row[x], t.k[r]);
         for (int j = 1; j <= r; j++) {
             const float pr = __fadd_rn((float)row[sv_clamp(x - j, 0, W - 1)], (float)row[sv_clamp(x + j, 0, W - 1)]);
-            acc = __fadd_rn(acc, __fmul_rn(pr, t.k[r + j]));
+            acc = __builtin_fmaf(pr, t.k[r + j], acc);
         }
     } else {
         acc = __fmul_rn(t.k[0], (float)row[sv_clamp(x - r, 0, W - 1)]);
-        for (int j = 1; j < t.n; j++) acc = __fadd_rn(acc, __fmul_rn(t.k[j], (float)row[sv_clamp(x + j - r, 0, W - 1)]));
+        for (int j = 1; j < t.n; j++) acc = __builtin_fmaf((float)row[sv_clamp(x + j - r, 0, W - 1)], t.k[j], acc);
     }
     return acc;
 }
@@ -329,11 +512,11 @@ __global__ void k_adaptive_threshold(const u8 *__restrict__ src, int H, int W, F
     if (x >= W) return;
     const u8 *s = src + (ptrdiff_t)blockIdx.z * H * W;
     const int r = t.n / 2;
-    float acc = __fadd_rn(__fmul_rn(t.k[r], row_value(s + (ptrdiff_t)y * W, x, W, t)), 0.f);
+    float acc = __fmul_rn(t.k[r], row_value(s + (ptrdiff_t)y * W, x, W, t));
     for (int j = 1; j <= r; j++) {
         const float lo = row_value(s + (ptrdiff_t)sv_clamp(y + j, 0, H - 1) * W, x, W, t);
         const float hi = row_value(s + (ptrdiff_t)sv_clamp(y - j, 0, H - 1) * W, x, W, t);
-        acc = __fadd_rn(acc, __fmul_rn(t.k[r + j], __fadd_rn(lo, hi)));
+        acc = __builtin_fmaf(__fadd_rn(lo, hi), t.k[r + j], acc);
     }
     const int mean = sv_clamp(__float2int_rn(acc), 0, 255);
     const int d = (int)s[(ptrdiff_t)y * W + x] - mean;
@@ -355,7 +538,17 @@ int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pi
         constexpr int FW = 64, FH = 64;
         const int aligned4 = (pitch % 4 == 0) && (img_stride % 4 == 0) && (W % 4 == 0) && ((uintptr_t)bgr % 4 == 0) && ((uintptr_t)binary % 4 == 0);
         dim3 grid((W + FW - 1) / FW, (H + FH - 1) / FH, n);
-        hipLaunchKernelGGL((k_preprocess_tiled<FW, FH, 256>), grid, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
+        static const int variant = getenv("SV_K1_VARIANT") ? atoi(getenv("SV_K1_VARIANT")) : 1;   // tuning aid
+        if (variant == 0)
+            hipLaunchKernelGGL((k_preprocess_tiled<FW, FH, 256>), grid, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
+        else if (variant == 1)
+            hipLaunchKernelGGL((k_preprocess_f32<64, 64, 512, 3, 2>), grid, dim3(512), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
+        else if (variant == 2)
+            hipLaunchKernelGGL((k_preprocess_f32<64, 64, 256, 7, 4>), grid, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
+        else {
+            dim3 grid32((W + 63) / 64, (H + 31) / 32, n);
+            hipLaunchKernelGGL((k_preprocess_f32<64, 32, 256, 4, 2>), grid32, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
+        }
     }
     SV_LAUNCH_CHECK("k_preprocess");
     return SV_OK;

@@ -1,0 +1,111 @@
+"""End-to-end frame -> digits pipeline with the host corner search in the loop -- the build's counterpart
+of the hot section of pipeline/run.py:244-312 (call order, glue, output conventions), batched and
+software-pipelined for a resident pool of frames:
+
+    GPU  K1 (binary)  --D2H, pinned-->  CPU contour corner search (threads)  --Minv, H2D-->  GPU  K2 -> K3
+
+Chunks of frames are double-buffered: while the host searches chunk i, the GPU thresholds chunk i+1 and
+classifies chunk i-1.  A frame whose grid is not found gets found=False and digits 0 (the reference
+returns "Grid detection failed" for it, pipeline/run.py:268-272)."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import host
+from .runtime import Context
+
+
+class FramePipeline:
+    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1):
+        self.ctx, self.H, self.W, self.chunk = ctx, H, W, chunk
+        self.host_threads = host_threads or max(1, (os.cpu_count() or 2) - 1)
+        self.min_area_ratio = min_area_ratio
+        dev = ctx.device
+        self.s_pre = torch.cuda.Stream(dev)       # K1 + D2H
+        self.s_cls = torch.cuda.Stream(dev)       # H2D + K2 + K3
+        self.pinned = [torch.empty((chunk, H, W), dtype=torch.uint8).pin_memory() for _ in range(3)]
+        self.dev_bin = [torch.empty((chunk, H, W), dtype=torch.uint8, device=dev) for _ in range(3)]
+        self.minv_pin = [torch.empty((chunk, 9), dtype=torch.float64).pin_memory() for _ in range(3)]
+        self.minv_dev = [torch.empty((chunk, 9), dtype=torch.float64, device=dev) for _ in range(3)]
+        self.pool = ThreadPoolExecutor(1)
+        ctx.reserve(chunk * 81)
+
+    def _search(self, slot, m, ev):
+        ev.synchronize()
+        corners, found = host.find_grid_corners_batch(self.pinned[slot][:m].numpy(), self.min_area_ratio, 0.02, self.host_threads)
+        safe = corners.astype(np.float32)
+        safe[~found] = np.array([[0, 0], [449, 0], [449, 449], [0, 449]], np.float32)      # any valid quad; result is masked
+        self.minv_pin[slot][:m] = torch.from_numpy(Context.corners_to_minv(safe).reshape(m, 9))
+        return corners, found
+
+    def run(self, frames, out=None):
+        """frames u8 [n,H,W,3] on the context's device -> dict(digits u8[n,81], logits f32[n,81,10], conf f32[n,81],
+        corners int32[n,4,2] (host), found bool[n] (host))."""
+        n = frames.shape[0]
+        dev = self.ctx.device
+        if out is None:
+            out = {"logits": torch.empty((n, 81, 10), dtype=torch.float32, device=dev),
+                   "digits": torch.empty((n, 81), dtype=torch.uint8, device=dev),
+                   "conf": torch.empty((n, 81), dtype=torch.float32, device=dev)}
+        corners_all = np.zeros((n, 4, 2), np.int32)
+        found_all = np.zeros(n, bool)
+        cur = torch.cuda.current_stream(dev)
+        self.s_pre.wait_stream(cur)
+        self.s_cls.wait_stream(cur)
+        starts = list(range(0, n, self.chunk))
+        pending = []                                  # (future, slot, start, m)
+        free_ev = [None, None, None]                  # classification done with slot's minv buffer
+
+        def classify(item):
+            fut, slot, s, m = item
+            corners, found = fut.result()
+            corners_all[s:s + m], found_all[s:s + m] = corners, found
+            with torch.cuda.stream(self.s_cls):
+                self.minv_dev[slot][:m].copy_(self.minv_pin[slot][:m], non_blocking=True)
+                sub = {k: out[k][s:s + m] for k in ("logits", "digits", "conf")}
+                self.ctx.frames_to_digits(frames[s:s + m], self.minv_dev[slot][:m], out=sub)
+                if not found.all():
+                    out["digits"][s:s + m][torch.from_numpy(~found).to(dev)] = 0
+                ev = torch.cuda.Event()
+                ev.record(self.s_cls)
+                free_ev[slot] = ev
+
+        for i, s in enumerate(starts):
+            slot = i % 3
+            m = min(self.chunk, n - s)
+            if free_ev[slot] is not None:
+                free_ev[slot].synchronize()
+            with torch.cuda.stream(self.s_pre):
+                b = self.ctx.preprocess(frames[s:s + m])
+                self.pinned[slot][:m].copy_(b, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.s_pre)
+            pending.append((self.pool.submit(self._search, slot, m, ev), slot, s, m))
+            if len(pending) > 1:
+                classify(pending.pop(0))
+        while pending:
+            classify(pending.pop(0))
+        cur.wait_stream(self.s_cls)
+        out["corners"], out["found"] = corners_all, found_all
+        return out
+
+
+def recognize_image(image, model_state_dict=None, ctx=None):
+    """One BGR image (numpy uint8 [H,W,3]) -> dict(grid 9x9 list, digits, confidences, corners) or None when no
+    grid is found -- the call order of pipeline/run.py:261-312 with preprocess_cell (CLAHE, row N1) left out."""
+    from .runtime import default_context
+    ctx = ctx or default_context()
+    if model_state_dict is not None:
+        ctx.load_state_dict(model_state_dict)
+    frames = torch.from_numpy(np.ascontiguousarray(image)).to(ctx.device)[None]
+    binary = ctx.preprocess(frames)[0].cpu().numpy()
+    corners = host.find_grid_corners(binary)
+    if corners is None:
+        return None
+    minv = ctx.minv_to_device(Context.corners_to_minv(corners[None].astype(np.float32)))
+    out = ctx.frames_to_digits(frames, minv)
+    digits = out["digits"][0].cpu().numpy()
+    return {"grid": [[int(digits[r * 9 + c]) for c in range(9)] for r in range(9)], "digits": digits,
+            "confidence": out["conf"][0].cpu().numpy(), "logits": out["logits"][0].cpu().numpy(), "corners": corners}

@@ -3,7 +3,7 @@ whatever device is asked for (GPU for bench.py, CPU for the small oracle tests).
 
 Each frame: paper-like background (per-frame level 170-230, a low-frequency illumination gradient,
 N(0,4) noise), a dark-lined 9x9 grid whose corners are a random perspective jitter (+-8 % of the side)
-of a square of ~0.83*H centred in the frame, ~30 of 81 cells filled with 5x7 block glyphs.
+of a square of 0.76*H centred in the frame (always fully inside it), ~30 of 81 cells filled with 5x7 block glyphs.
 Returns the generator's ground truth corners (TL,TR,BR,BL) so the device-only metric does not depend
 on the host corner search.
 """
@@ -51,8 +51,8 @@ def _homography(src, dst):
 def synth_frames(n, H=1080, W=1920, seed=1234, device="cpu", chunk=8):
     """-> frames u8 [n,H,W,3] (BGR, on `device`), corners f32 [n,4,2] (numpy), puzzle u8 [n,9,9] (numpy)."""
     rs = np.random.RandomState(seed)
-    side = 0.83 * min(H, W)
-    cx, cy = W / 2 + rs.uniform(-0.03, 0.03, n) * W, H / 2 + rs.uniform(-0.03, 0.03, n) * H
+    side = 0.76 * min(H, W)
+    cx, cy = W / 2 + rs.uniform(-0.03, 0.03, n) * W, H / 2 + rs.uniform(-0.02, 0.02, n) * H
     base = np.stack([np.stack([cx - side / 2, cy - side / 2], 1), np.stack([cx + side / 2, cy - side / 2], 1),
                      np.stack([cx + side / 2, cy + side / 2], 1), np.stack([cx - side / 2, cy + side / 2], 1)], 1)
     corners = base + rs.uniform(-0.08, 0.08, (n, 4, 2)) * side

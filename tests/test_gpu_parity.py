@@ -188,3 +188,32 @@ def test_dropin_numpy_functions(ctx):
     cells = extract_cells(warped)
     assert isinstance(cells, list) and len(cells) == 81 and all(c.shape == (28, 28) and c.dtype == np.uint8 for c in cells)
     assert (np.stack(cells) == o.extract_cells(warped)).all()
+
+
+def test_pipeline_with_host_corner_search(ctx, golden_dir):
+    """K1 -> D2H -> host corner search -> K2 -> K3, chunked and double-buffered, against the oracle run end to end."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.pipeline import FramePipeline, recognize_image
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    ctx.load_state_dict(sd)
+    frames, corners_gt, _ = _frames(7, 540, 960, seed=31)
+    frames[3] = 200                                                   # a frame without a grid
+    pipe = FramePipeline(ctx, 540, 960, chunk=3, host_threads=2)
+    out = pipe.run(frames)
+    torch.cuda.synchronize()
+    host = frames.cpu().numpy()
+    assert out["found"].tolist() == [True, True, True, False, True, True, True]
+    for i in range(7):
+        if i == 3:
+            assert (out["digits"][i].cpu().numpy() == 0).all()
+            continue
+        c = o.find_grid_contour(o.preprocess_for_grid_detection(host[i]))
+        assert (out["corners"][i] == c).all()
+        cells = o.warp_cells(host[i], c.astype(np.float32))
+        el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(cells)[:, None])
+        assert np.abs(out["logits"][i].cpu().numpy() - el.numpy()).max() <= LOGIT_TOL
+        assert (out["digits"][i].cpu().numpy() == ed.numpy()).all()
+    one = recognize_image(host[0], ctx=ctx)
+    assert (one["digits"] == out["digits"][0].cpu().numpy()).all() and len(one["grid"]) == 9
+    assert recognize_image(host[3], ctx=ctx) is None

@@ -79,16 +79,15 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd import sharding
+    rank, local_rank, world = sharding.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    sharding.init("nccl")          # RCCL; only for the timing barrier and the MAX of elapsed
+    dev = torch.device("cuda", local_rank)
 
-    import sudoku_vision_amd as sva
     from sudoku_vision_amd.synth import synth_frames
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cnn_oracle
@@ -111,10 +110,7 @@ def main():
         return binary
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sharding.barrier(dev)
 
     for _ in range(args.warmup):
         step()
@@ -126,10 +122,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     per_kernel = ctx.timing_end()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dev)
 
     # second figure: the same pool with the host corner search in the loop (K1 -> D2H -> CPU contours -> K2 -> K3)
     e2e = None
@@ -144,10 +137,7 @@ def main():
             res_e2e = pipe.run(frames, out=out)
         barrier()
         dt = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = sharding.max_over_ranks(dt, dev)
         err = np.abs(res_e2e["corners"].astype(np.float32)[:, :, None, :] - corners[:, None, :, :]).sum(-1).min(-1).max()
         e2e = {"value": n * args.e2e_passes * world / dt, "unit": "frames/s", "host_threads_per_gpu": host_threads,
                "grids_found": int(res_e2e["found"].sum()), "of": n, "max_corner_error_px": float(err),

@@ -16,6 +16,7 @@
 // per-lane register order the kernels load.
 #include "sv_device.h"
 #include "sv_internal.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -138,6 +139,144 @@ __global__ __launch_bounds__(256, 2) void k_conv_features(const void *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Producer/consumer form of the same kernel: one 512-thread workgroup per CU, software-pipelined over
+// cell pairs with ONE barrier per pair.
+//   waves 0-3 (consumers): conv2 of pair i on the MFMA pipe, from c1[i & 1]           (weights in VGPRs)
+//   waves 4-7 (producers): conv1 of pair i+1 on the VALU into c1[(i+1) & 1], and the 28x28 inputs of
+//                          pair i+2 into in_s[i & 1]
+// The matrix pipe and the vector pipe of a SIMD run side by side, so the consumers never leave the
+// MFMA stream for conv1 or for input staging.  LDS: 2 x 65,792 (conv1 planes) + 2 x 7,200 (inputs) B.
+// ---------------------------------------------------------------------------------------------------
+template <bool U8IN>
+__global__ __launch_bounds__(512, 2) void k_conv_features_pc(const void *__restrict__ xin, long B,
+                                                             const float *__restrict__ w1, const float *__restrict__ b1,
+                                                             const float *__restrict__ w2reg, const float *__restrict__ b2,
+                                                             float *__restrict__ feat)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4 * IN_CELL + 4 * C1_CELL];
+    float *in_base = lds;                 // [2 buffers][2 cells][900]
+    float *c1_base = lds + 4 * IN_CELL;   // [2 buffers][2 cells][32][257]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int np = (wave >> 1) & 1, par = wave & 1;   // consumer roles
+    const int pw = wave & 3, ptid = tid & 255;        // producer roles
+
+    float breg[2][72];
+    float bias2_0 = 0.f, bias2_1 = 0.f;
+    if (consumer) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int ks = 0; ks < 72; ks++) breg[t][ks] = w2reg[((np * 2 + t) * 72 + ks) * 64 + lane];
+        bias2_0 = b2[32 * np + (lane & 15)];
+        bias2_1 = b2[32 * np + 16 + (lane & 15)];
+    }
+    for (int i = tid; i < 4 * IN_CELL + 4 * C1_CELL; i += 512) lds[i] = 0.f;   // zero borders, for good
+    __syncthreads();
+
+    const long npairs = (B + 1) / 2;
+    const long first = blockIdx.x, stride = gridDim.x;
+    const long iters = first < npairs ? (npairs - first + stride - 1) / stride : 0;
+
+    auto stage = [&](long it) {          // producers: inputs of local iteration `it` -> in_s[it & 1]
+        const long pair = first + it * stride;
+        float *in_s = in_base + (it & 1) * 2 * IN_CELL;
+        for (int i = ptid; i < 2 * 784; i += 256) {
+            const int cl = i / 784, p = i - cl * 784, y = p / 28, x = p - y * 28;
+            long cg = pair * 2 + cl;
+            if (cg >= B) cg = B - 1;
+            float v;
+            if (U8IN) v = glue_norm(((const u8 *)xin)[cg * 784 + p]);
+            else v = ((const float *)xin)[cg * 784 + p];
+            in_s[cl * IN_CELL + (y + 1) * IN_W + x + 1] = v;
+        }
+    };
+    auto conv1 = [&](long it) {          // producers: in_s[it & 1] -> c1[it & 1]
+        const float *in_s = in_base + (it & 1) * 2 * IN_CELL;
+        float *c1 = c1_base + (it & 1) * 2 * C1_CELL;
+        for (int rnd = 0; rnd < 7; rnd++) {
+            const int idx = rnd * 64 + lane;
+            if (idx < 392) {
+                const int cl = idx / 196, pp = idx - cl * 196, py = pp / 14, px = pp - py * 14;
+                float patch[4][4];
+                const float *src = in_s + cl * IN_CELL + (2 * py) * IN_W + 2 * px;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) patch[i][j] = src[i * IN_W + j];
+                float *dstp = c1 + cl * C1_CELL + (py + 1) * 16 + px + 1;
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    const int oc = pw * 8 + o;
+                    const float *w = w1 + oc * 9;
+                    const float bias = b1[oc];
+                    float m = -3.0e38f;
+#pragma unroll
+                    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                        for (int dx = 0; dx < 2; dx++) {
+                            float acc = bias;
+#pragma unroll
+                            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                                for (int kx = 0; kx < 3; kx++) acc = __builtin_fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
+                            m = fmaxf(m, acc);
+                        }
+                    dstp[oc * PLANE] = fmaxf(m, 0.f);
+                }
+            }
+        }
+    };
+
+    // prologue: fill the pipeline
+    if (!consumer && iters > 0) stage(0);
+    __syncthreads();
+    if (!consumer) {
+        if (iters > 0) conv1(0);
+        if (iters > 1) stage(1);
+    }
+    __syncthreads();
+
+    for (long it = 0; it < iters; it++) {
+        if (consumer) {
+            const long pair = first + it * stride;
+            const float *c1 = c1_base + (it & 1) * 2 * C1_CELL;
+            for (int j = par; j < 25; j += 2) {
+                const int i16 = lane & 15, q = lane >> 4;
+                int g = 4 * j + (i16 >> 2);
+                if (g > 97) g = 97;
+                const int cl = g >= 49 ? 1 : 0, wl = g - 49 * cl, wy = wl / 7, wx = wl - 7 * wy, s = i16 & 3;
+                const float *ap = c1 + cl * C1_CELL + q * 8 * PLANE + (2 * wy + (s >> 1)) * 16 + 2 * wx + (s & 1);
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 72; ks++) {
+                    const int tap = ks >> 3, icb = ks & 7;
+                    const float a = ap[icb * PLANE + (tap / 3) * 16 + (tap % 3)];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[0][ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[1][ks], acc1, 0, 0, 0);
+                }
+                const int gw = 4 * j + q;
+                if (gw < 98) {
+                    const int ocl = gw >= 49 ? 1 : 0, owl = gw - 49 * ocl;
+                    const long cg = pair * 2 + ocl;
+                    if (cg < B) {
+                        float *o = feat + cg * FEAT + owl * 64 + 32 * np + i16;
+                        o[0] = fmaxf(fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc0[2], acc0[3])) + bias2_0, 0.f);
+                        o[16] = fmaxf(fmaxf(fmaxf(acc1[0], acc1[1]), fmaxf(acc1[2], acc1[3])) + bias2_1, 0.f);
+                    }
+                }
+            }
+        } else {
+            if (it + 1 < iters) conv1(it + 1);
+            if (it + 2 < iters) stage(it + 2);
+        }
+        __syncthreads();
+    }
+}
+
 // 64 cells per workgroup, 16 per wave; K = 3136 in 196 chunks of 16.
 __global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat, long B, const float *__restrict__ w1reg,
                                                  const float *__restrict__ b1, const float *__restrict__ w2,
@@ -215,7 +354,15 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *log
     const sv_weights &w = ctx->w;
     const long npairs = (B + 1) / 2;
     const int grid = (int)(npairs < 2L * ctx->num_cus ? npairs : 2L * ctx->num_cus);
-    {
+    static const int conv_variant = getenv("SV_CONV_VARIANT") ? atoi(getenv("SV_CONV_VARIANT")) : 1;   // tuning aid
+    if (conv_variant == 1) {
+        const int grid_pc = (int)(npairs < (long)ctx->num_cus ? npairs : (long)ctx->num_cus);
+        sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
+        if (x_is_u8)
+            hipLaunchKernelGGL(k_conv_features_pc<true>, dim3(grid_pc), dim3(512), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
+        else
+            hipLaunchKernelGGL(k_conv_features_pc<false>, dim3(grid_pc), dim3(512), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
+    } else {
     sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
     if (x_is_u8)
         hipLaunchKernelGGL(k_conv_features<true>, dim3(grid), dim3(256), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);

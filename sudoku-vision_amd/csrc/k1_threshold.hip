@@ -460,6 +460,145 @@ __global__ __launch_bounds__(NT) void k_preprocess_f32(const u8 *__restrict__ bg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The marching variant: no LDS tiles, no barriers.  One WAVE owns a 256-pixel-wide strip (64 lanes x 4
+// pixels; the outer 2 lanes on each side are halo, so 240 output columns) and marches down a band of
+// rows.  Per input row it loads 12 B per lane, converts to gray, does the horizontal 1-4-6-4-1 with DPP
+// neighbour exchange, keeps the last five h-rows in registers for the vertical 1-4-6-4-1, runs the 11-tap
+// f32 row pass on the fresh blurred row (again DPP), and pushes the result into an 11-row register ring
+// from which the f32 column pass + threshold of the row five pushes back is emitted.  The only memory
+// besides the frame and the output is a per-wave LDS delay line that returns the blurred row (the
+// threshold's `src`) five rows later.  Vertical REPLICATE = pushing the first/last row several times.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pick4(const f32x4_t &v, int e) { return e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3]; }
+
+constexpr int MARCH_STRIP = 240;   // output columns per wave
+
+// Requires W % 4 == 0 and 4-byte aligned rows (aligned4); other shapes use the tiled kernel.
+// Straight-line per-row body: no memory operation sits under a divergent or data-dependent branch, so the
+// compiler can keep PF row loads in flight (counted s_waitcnt vmcnt) instead of draining the queue.
+__global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
+                                                          u8 *__restrict__ out, Taps11 taps, int TH, int nstrips, int nbands, int nitems)
+{
+    __shared__ __attribute__((aligned(16))) f32x4_t sdl[4][8][64];   // per-wave delay line of blurred rows
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= nitems) return;
+    const int strip = item % nstrips, band = (item / nstrips) % nbands, frame = item / (nstrips * nbands);
+    const u8 *img = bgr + (ptrdiff_t)frame * img_stride;
+    u8 *dst = out + (ptrdiff_t)frame * H * W;
+
+    const int xs0 = strip * MARCH_STRIP - 8;
+    const int cx0 = xs0 + 4 * lane;
+    const int ldx = 3 * sv_clamp(cx0, 0, W - 4);             // every lane loads an in-bounds, aligned pixel group
+    const bool edge_l = xs0 < 0, edge_r = xs0 + 256 > W;    // wave-uniform
+    const int yb = band * TH, ye = (yb + TH < H) ? yb + TH : H;
+    const int qs = sv_clamp(yb - 5, 0, H - 1);              // first blurred row this wave produces
+    const int N = (ye + 4) - qs + 1;                        // pushes: rows qs .. ye+4 (rows > H-1 are REPLICATE repeats of H-1)
+    const int emit_from = yb + 5 - qs;                      // push index whose window centre is output row yb
+    const int srcl_hi = (W - 1 - xs0) >> 2;                 // lane holding column W-1 (element 3 since W % 4 == 0)
+
+    auto load_raw = [&](int gy) -> u32x3 { return *(const u32x3 *)(img + (ptrdiff_t)sv_reflect101(gy, H) * pitch + ldx); };
+    // gray + horizontal 1-4-6-4-1 -> 4 un-normalised h values
+    auto hrow = [&](const u32x3 &d) -> f32x4_t {
+        float p0 = gray_f32((float)(d.a & 255), (float)((d.a >> 8) & 255), (float)((d.a >> 16) & 255));
+        float p1 = gray_f32((float)(d.a >> 24), (float)(d.b & 255), (float)((d.b >> 8) & 255));
+        float p2 = gray_f32((float)((d.b >> 16) & 255), (float)(d.b >> 24), (float)(d.c & 255));
+        float p3 = gray_f32((float)((d.c >> 8) & 255), (float)((d.c >> 16) & 255), (float)(d.c >> 24));
+        if (edge_l) {            // REFLECT_101: columns -2,-1 are columns 2,1 (held by the next lane)
+            const float n1 = lane_next(p1), n2 = lane_next(p2);
+            if (cx0 == -4) { p2 = n2; p3 = n1; }
+        }
+        if (edge_r) {            // columns W, W+1 are columns W-2, W-3 (held by the previous lane)
+            const float q1 = lane_prev(p1), q2 = lane_prev(p2);
+            if (cx0 == W) { p0 = q2; p1 = q1; }
+        }
+        const float l2 = lane_prev(p2), l3 = lane_prev(p3), r0 = lane_next(p0), r1 = lane_next(p1);
+        f32x4_t h;
+        h[0] = blur5(l2, l3, p0, p1, p2);
+        h[1] = blur5(l3, p0, p1, p2, p3);
+        h[2] = blur5(p0, p1, p2, p3, r0);
+        h[3] = blur5(p1, p2, p3, r0, r1);
+        return h;
+    };
+    // blurred row (as f32) from the 5-row window, with the horizontal REPLICATE of the blurred image, and its f32 row pass
+    auto finish_row = [&](const f32x4_t &a, const f32x4_t &b, const f32x4_t &c, const f32x4_t &d, const f32x4_t &e, f32x4_t &bfv, f32x4_t &rwv) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) bfv[i] = floorf(__builtin_fmaf(blur5(a[i], b[i], c[i], d[i], e[i]), 1.f / 256.f, 0.5f));
+        if (edge_l) {
+            const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bfv[0]), 2));   // column 0 = lane 2, element 0
+            if (cx0 < 0) { bfv[0] = v0; bfv[1] = v0; bfv[2] = v0; bfv[3] = v0; }
+        }
+        if (edge_r) {
+            const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bfv[3]), srcl_hi));
+            if (cx0 >= W) { bfv[0] = v1; bfv[1] = v1; bfv[2] = v1; bfv[3] = v1; }
+        }
+        f32x4_t pv, nx;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { pv[i] = lane_prev(bfv[i]); nx[i] = lane_next(bfv[i]); }
+        const float pp3 = lane_prev(pv[3]), nn0 = lane_next(nx[0]);
+        const float v[14] = {pp3, pv[0], pv[1], pv[2], pv[3], bfv[0], bfv[1], bfv[2], bfv[3], nx[0], nx[1], nx[2], nx[3], nn0};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float acc = __fmul_rn(taps.k[0], v[i]);
+#pragma unroll
+            for (int j = 1; j < 11; j++) acc = __builtin_fmaf(v[i + j], taps.k[j], acc);
+            rwv[i] = acc;
+        }
+    };
+
+    // prime: h rows qs-2 .. qs+1, and PF further image rows in flight
+    constexpr int PF = 4;
+    f32x4_t h0, h1 = hrow(load_raw(qs - 2)), h2 = hrow(load_raw(qs - 1)), h3 = hrow(load_raw(qs)), h4 = hrow(load_raw(qs + 1));
+    u32x3 raw[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) raw[i] = load_raw(qs + 2 + i);
+
+    f32x4_t cur_rw = {0.f, 0.f, 0.f, 0.f}, cur_bf = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t win[11];
+
+    for (int base = 0; base < N; base += 11) {
+#pragma unroll
+        for (int ph = 0; ph < 11; ph++) {
+            const int i = base + ph;
+            if (i < N) {
+                const int q = qs + i;                            // blurred row of this push (rows > H-1 repeat row H-1)
+                const u32x3 raw_cur = raw[0];
+#pragma unroll
+                for (int k = 0; k + 1 < PF; k++) raw[k] = raw[k + 1];
+                raw[PF - 1] = load_raw(q + 2 + PF < H + 2 ? q + 2 + PF : H + 1);   // row that push i + PF will consume
+                h0 = h1; h1 = h2; h2 = h3; h3 = h4;
+                h4 = hrow(raw_cur);
+                f32x4_t nbf, nrw;
+                finish_row(h0, h1, h2, h3, h4, nbf, nrw);
+                if (q <= H - 1) { cur_bf = nbf; cur_rw = nrw; }   // (a select, not a branch: bottom REPLICATE pushes the last row again)
+                if (i == 0) {
+#pragma unroll
+                    for (int k = 0; k < 11; k++) win[k] = cur_rw;   // top REPLICATE: rows above the first one read the first one
+                }
+                win[ph] = cur_rw;
+                sdl[wave][i & 7][lane] = cur_bf;
+                if (i >= emit_from) {                            // emit output row yo; its window centre was pushed 5 pushes ago
+                    const int yo = q - 5;
+                    const f32x4_t srcv = sdl[wave][(i - 5) & 7][lane];
+                    u32 o = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        float acc = __fmul_rn(taps.k[5], win[(ph + 6) % 11][c]);
+#pragma unroll
+                        for (int j = 1; j <= 5; j++)
+                            acc = __builtin_fmaf(__fadd_rn(win[(ph + 6 + j) % 11][c], win[(ph + 6 + 11 - j) % 11][c]), taps.k[5 + j], acc);
+                        o |= (__fsub_rn(rintf(acc), srcv[c]) >= 2.f ? 255u : 0u) << (8 * c);
+                    }
+                    if (lane >= 2 && lane < 62 && cx0 < W) *(u32 *)(dst + (ptrdiff_t)yo * W + cx0) = o;
+                }
+            }
+        }
+    }
+}
+
 __global__ void k_gray(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *__restrict__ gray)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -538,10 +677,20 @@ int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pi
         constexpr int FW = 64, FH = 64;
         const int aligned4 = (pitch % 4 == 0) && (img_stride % 4 == 0) && (W % 4 == 0) && ((uintptr_t)bgr % 4 == 0) && ((uintptr_t)binary % 4 == 0);
         dim3 grid((W + FW - 1) / FW, (H + FH - 1) / FH, n);
-        static const int variant = getenv("SV_K1_VARIANT") ? atoi(getenv("SV_K1_VARIANT")) : 1;   // tuning aid
-        if (variant == 0)
+        static const int variant = getenv("SV_K1_VARIANT") ? atoi(getenv("SV_K1_VARIANT")) : 4;   // tuning aid
+        if (variant == 4 && aligned4) {
+            const int nstrips = (W + MARCH_STRIP - 1) / MARCH_STRIP;
+            static const int want_waves = getenv("SV_K1_WAVES") ? atoi(getenv("SV_K1_WAVES")) : 10240;   // 2 rounds of 5 waves/SIMD
+            int nbands = (want_waves + n * nstrips - 1) / (n * nstrips);
+            if (nbands > H / 32) nbands = H / 32;
+            if (nbands < 1) nbands = 1;
+            const int TH = (H + nbands - 1) / nbands;
+            nbands = (H + TH - 1) / TH;
+            const int nitems = n * nstrips * nbands;
+            hipLaunchKernelGGL(k_preprocess_march, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, TH, nstrips, nbands, nitems);
+        } else if (variant == 0)
             hipLaunchKernelGGL((k_preprocess_tiled<FW, FH, 256>), grid, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
-        else if (variant == 1)
+        else if (variant == 1 || variant == 4)
             hipLaunchKernelGGL((k_preprocess_f32<64, 64, 512, 3, 2>), grid, dim3(512), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
         else if (variant == 2)
             hipLaunchKernelGGL((k_preprocess_f32<64, 64, 256, 7, 4>), grid, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);

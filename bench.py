@@ -161,10 +161,14 @@ def main():
                              "achieved": ach / (1e9 if bound == "hbm" else 1e12), "peak": peak / (1e9 if bound == "hbm" else 1e12),
                              "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": ach / peak}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(dom)
+        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected
+        # as MI355X_MICROARCH.md prescribes; collected on this same command at 256 frames, profiles/pmc_traffic.json)
+        traffic, tf = None, os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf) and n == 256:
+            pmc = json.load(open(tf))
+            traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+            for k in kernels:
+                kernels[k]["traffic"] = pmc.get(k, {}).get("hbm_bytes_per_launch")
         roofline = {"kernel": dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")}, "traffic": traffic}
         res = {
             "metric": "end-to-end frames/sec (1080p->81 digits)", "value": fps, "unit": "frames/s",

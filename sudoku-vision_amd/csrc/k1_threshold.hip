@@ -12,7 +12,6 @@
 // then fma(below + above, k_j, s) outward), so the output is bit-identical to the CPU oracle.
 #include "sv_device.h"
 #include "sv_internal.h"
-#include <cstdlib>
 
 namespace {
 
@@ -89,197 +88,14 @@ __global__ __launch_bounds__(256) void k_preprocess_any(const u8 *__restrict__ b
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// The fast path.  One workgroup per TW x TH output tile; every stage works on 4-pixel groups so that
-// global and LDS accesses are whole dwords (12 B of BGR -> 4 gray bytes -> 4 u16 -> 4 bytes -> 4 f32).
-// Column index space of every LDS array starts at x0-8 (a multiple of 4), rows at y0-7.
-//   A  gray      g8 [TH+14][TW+16] u8    global_load_dwordx3 per group, coalesced
-//   B  h 1-4-6-4-1        hb [TH+14][TW+16] u16   (un-normalised, <= 4080)
-//   C  v 1-4-6-4-1, (v+128)>>8   bl8 [TH+10][TW+16] u8   sliding window down the column
-//      (edge tiles only: REPLICATE fix-up of the blurred halo)
-//   D  f32 row pass, taps left to right  rw [TH+10][TW] f32   (aliases g8/hb)
-//   E  f32 column pass (centre, then pairs), round-half-even, threshold -> global dword stores
-// ---------------------------------------------------------------------------------------------------
 typedef unsigned int u32;
 struct __attribute__((packed, aligned(4))) u32x3 { u32 a, b, c; };
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
-
-template <int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_preprocess_tiled(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch,
-                                                         ptrdiff_t img_stride, u8 *__restrict__ out, Taps11 taps, int aligned4)
-{
-    constexpr int GW = TW + 16, GH = TH + 14, BH = TH + 10, NG = GW / 4, NK = TW / 4;
-    constexpr int RC = 6;   // output rows per thread in stage C
-    constexpr int RE = 4;   // output rows per thread in stage E
-    static_assert(BH % RC == 0 || true, "");
-    constexpr int REGION1 = (GH * GW * 3 > BH * TW * 4) ? GH * GW * 3 : BH * TW * 4;
-    __shared__ __attribute__((aligned(16))) u8 smem[REGION1 + BH * GW];
-    u32 *g8d = (u32 *)smem;                       // [GH][NG]
-    u32 *hbd = (u32 *)(smem + GH * GW);           // [GH][NG*2]  (2 dwords = 4 u16 per group)
-    float *rw = (float *)smem;                    // [BH][TW]    (written after g8/hb are dead)
-    u32 *bl8d = (u32 *)(smem + REGION1);          // [BH][NG]
-    u8 *bl8 = smem + REGION1;
-
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const u8 *img = bgr + (ptrdiff_t)blockIdx.z * img_stride;
-    u8 *dst = out + (ptrdiff_t)blockIdx.z * H * W;
-
-    // ---- A: gray
-    for (int it = tid; it < GH * NG; it += NT) {
-        const int ly = it / NG, g = it - ly * NG;
-        const int gx = x0 - 8 + 4 * g;
-        const int sy = sv_reflect101(sv_clamp(y0 - 7 + ly, -2, H + 1), H);
-        const u8 *row = img + (ptrdiff_t)sy * pitch;
-        u32 px;
-        if (aligned4 && gx >= 0 && gx + 3 < W) {
-            const u32x3 d = *(const u32x3 *)(row + 3 * gx);
-            const int p0 = sv_gray_px(d.a & 255, (d.a >> 8) & 255, (d.a >> 16) & 255);
-            const int p1 = sv_gray_px(d.a >> 24, d.b & 255, (d.b >> 8) & 255);
-            const int p2 = sv_gray_px((d.b >> 16) & 255, d.b >> 24, d.c & 255);
-            const int p3 = sv_gray_px((d.c >> 8) & 255, (d.c >> 16) & 255, d.c >> 24);
-            px = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
-        } else {
-            px = 0;
-            for (int i = 0; i < 4; i++) {
-                const int sx = sv_reflect101(sv_clamp(gx + i, -2, W + 1), W);
-                const u8 *p = row + (ptrdiff_t)sx * 3;
-                px |= (u32)sv_gray_px(p[0], p[1], p[2]) << (8 * i);
-            }
-        }
-        g8d[it] = px;
-    }
-    __syncthreads();
-
-    // ---- B: horizontal 1-4-6-4-1 (columns 0,1 and GW-2,GW-1 come out as don't-care)
-    for (int it = tid; it < GH * NG; it += NT) {
-        const int ly = it / NG, g = it - ly * NG;
-        const u32 w0 = g8d[ly * NG + (g > 0 ? g - 1 : 0)], w1 = g8d[it], w2 = g8d[ly * NG + (g < NG - 1 ? g + 1 : NG - 1)];
-        const int pm2 = (w0 >> 16) & 255, pm1 = w0 >> 24, q0 = w1 & 255, q1 = (w1 >> 8) & 255, q2 = (w1 >> 16) & 255, q3 = w1 >> 24,
-                  q4 = w2 & 255, q5 = (w2 >> 8) & 255;
-        const u32 h0 = (pm2 + q2) + 4 * (pm1 + q1) + 6 * q0;
-        const u32 h1 = (pm1 + q3) + 4 * (q0 + q2) + 6 * q1;
-        const u32 h2 = (q0 + q4) + 4 * (q1 + q3) + 6 * q2;
-        const u32 h3 = (q1 + q5) + 4 * (q2 + q4) + 6 * q3;
-        u32x2_t o = {h0 | (h1 << 16), h2 | (h3 << 16)};
-        *(u32x2_t *)(hbd + 2 * it) = o;
-    }
-    __syncthreads();
-
-    // ---- C: vertical 1-4-6-4-1 with a sliding window, normalise: (v + 128) >> 8
-    {
-        constexpr int NCH = (BH + RC - 1) / RC;
-        for (int it = tid; it < NCH * NG; it += NT) {
-            const int ch = it / NG, g = it - ch * NG;
-            const int br0 = ch * RC;
-            u32 win[RC + 4][4];
-#pragma unroll
-            for (int r = 0; r < RC + 4; r++) {
-                const int row = br0 + r < GH ? br0 + r : GH - 1;
-                const u32x2_t v = *(const u32x2_t *)(hbd + 2 * (row * NG + g));
-                win[r][0] = v[0] & 0xffff; win[r][1] = v[0] >> 16; win[r][2] = v[1] & 0xffff; win[r][3] = v[1] >> 16;
-            }
-#pragma unroll
-            for (int r = 0; r < RC; r++) {
-                if (br0 + r < BH) {
-                    u32 o = 0;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const u32 v = (win[r][c] + win[r + 4][c]) + 4 * (win[r + 1][c] + win[r + 3][c]) + 6 * win[r + 2][c];
-                        o |= ((v + 128) >> 8) << (8 * c);
-                    }
-                    bl8d[(br0 + r) * NG + g] = o;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- edge tiles: blurred halo outside the image = REPLICATE of the blurred image
-    if (x0 < 5 || x0 + TW + 5 > W || y0 < 5 || y0 + TH + 5 > H) {
-        for (int it = tid; it < BH * GW; it += NT) {
-            const int br = it / GW, c = it - br * GW;
-            const int q = x0 - 8 + c;
-            if (q < 0 || q >= W) {
-                const int sc = sv_clamp(q, 0, W - 1) - (x0 - 8);
-                if (sc >= 0 && sc < GW) bl8[br * GW + c] = bl8[br * GW + sc];
-            }
-        }
-        __syncthreads();
-        for (int it = tid; it < BH * NG; it += NT) {
-            const int br = it / NG, g = it - br * NG;
-            const int r = y0 - 5 + br;
-            if (r < 0 || r >= H) {
-                const int sr = sv_clamp(r, 0, H - 1) - (y0 - 5);
-                if (sr >= 0 && sr < BH) bl8d[it] = bl8d[sr * NG + g];
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- D: f32 row pass.  Outputs x = 4k..4k+3 read blurred columns 4k+3 .. 4k+16 (array index space)
-    f32x4_t *rw4 = (f32x4_t *)rw;
-    for (int it = tid; it < BH * NK; it += NT) {
-        const int br = it / NK, k = it - br * NK;
-        const u32 *src = bl8d + br * NG + k;
-        const u32 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3], w4 = src[4];
-        float v[14];
-        v[0] = (float)(w0 >> 24);
-        v[1] = (float)(w1 & 255); v[2] = (float)((w1 >> 8) & 255); v[3] = (float)((w1 >> 16) & 255); v[4] = (float)(w1 >> 24);
-        v[5] = (float)(w2 & 255); v[6] = (float)((w2 >> 8) & 255); v[7] = (float)((w2 >> 16) & 255); v[8] = (float)(w2 >> 24);
-        v[9] = (float)(w3 & 255); v[10] = (float)((w3 >> 8) & 255); v[11] = (float)((w3 >> 16) & 255); v[12] = (float)(w3 >> 24);
-        v[13] = (float)(w4 & 255);
-        f32x4_t o;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float acc = __fmul_rn(taps.k[0], v[c]);
-#pragma unroll
-            for (int j = 1; j < 11; j++) acc = __builtin_fmaf(v[c + j], taps.k[j], acc);
-            o[c] = acc;
-        }
-        rw4[it] = o;
-    }
-    __syncthreads();
-
-    // ---- E: f32 column pass, round, compare, store
-    {
-        constexpr int NCH = (TH + RE - 1) / RE;
-        for (int it = tid; it < NCH * NK; it += NT) {
-            const int ch = it / NK, k = it - ch * NK;
-            const int yb = ch * RE;
-            f32x4_t win[RE + 10];
-#pragma unroll
-            for (int r = 0; r < RE + 10; r++) win[r] = rw4[(yb + r < BH ? yb + r : BH - 1) * NK + k];
-#pragma unroll
-            for (int r = 0; r < RE; r++) {
-                const int y = yb + r;
-                if (y >= TH || y0 + y >= H) continue;
-                const u32 srcw = bl8d[(y + 5) * NG + k + 2];
-                u32 o = 0;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    // (FilterEngine adds delta = +0.f here; every operand is >= +0, so the sum is unchanged)
-                    float acc = __fmul_rn(taps.k[5], win[r + 5][c]);
-#pragma unroll
-                    for (int j = 1; j <= 5; j++) acc = __builtin_fmaf(__fadd_rn(win[r + 5 + j][c], win[r + 5 - j][c]), taps.k[5 + j], acc);
-                    const int mean = sv_clamp(__float2int_rn(acc), 0, 255);
-                    const int sv = (int)((srcw >> (8 * c)) & 255);
-                    o |= (sv - mean <= -2 ? 255u : 0u) << (8 * c);
-                }
-                const int gx = x0 + 4 * k;
-                u8 *d = dst + (ptrdiff_t)(y0 + y) * W + gx;
-                if (aligned4 && gx + 3 < W) *(u32 *)d = o;
-                else
-                    for (int c = 0; c < 4; c++)
-                        if (gx + c < W) d[c] = (u8)(o >> (8 * c));
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
-// The float-pipe variant of the tiled kernel (the one the dispatcher uses).  gfx950 issues f32
+// The LDS-tiled kernel: any width/alignment (the marching kernel below needs W % 4 == 0).  One workgroup
+// per 64 x 64 output tile, every stage on 4-pixel groups; column index space of the LDS arrays starts at
+// x0-8, rows at y0-7.  gfx950 issues f32
 // add/mul/fma at full rate but VOP3 integer and conversion instructions at about half of it
 // (profiles/r01_ubench_valu_rates.txt), and every integer stage here is exact in f32 (all values
 // < 2^24), so after the byte -> float conversion everything runs on the f32 pipe:
@@ -677,26 +493,17 @@ int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pi
         constexpr int FW = 64, FH = 64;
         const int aligned4 = (pitch % 4 == 0) && (img_stride % 4 == 0) && (W % 4 == 0) && ((uintptr_t)bgr % 4 == 0) && ((uintptr_t)binary % 4 == 0);
         dim3 grid((W + FW - 1) / FW, (H + FH - 1) / FH, n);
-        static const int variant = getenv("SV_K1_VARIANT") ? atoi(getenv("SV_K1_VARIANT")) : 4;   // tuning aid
-        if (variant == 4 && aligned4) {
+        if (aligned4) {
             const int nstrips = (W + MARCH_STRIP - 1) / MARCH_STRIP;
-            static const int want_waves = getenv("SV_K1_WAVES") ? atoi(getenv("SV_K1_WAVES")) : 10240;   // 2 rounds of 5 waves/SIMD
-            int nbands = (want_waves + n * nstrips - 1) / (n * nstrips);
+            int nbands = (10240 + n * nstrips - 1) / (n * nstrips);      // ~2 rounds of 5 waves per SIMD on 256 CUs
             if (nbands > H / 32) nbands = H / 32;
             if (nbands < 1) nbands = 1;
             const int TH = (H + nbands - 1) / nbands;
             nbands = (H + TH - 1) / TH;
             const int nitems = n * nstrips * nbands;
             hipLaunchKernelGGL(k_preprocess_march, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, TH, nstrips, nbands, nitems);
-        } else if (variant == 0)
-            hipLaunchKernelGGL((k_preprocess_tiled<FW, FH, 256>), grid, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
-        else if (variant == 1 || variant == 4)
+        } else {
             hipLaunchKernelGGL((k_preprocess_f32<64, 64, 512, 3, 2>), grid, dim3(512), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
-        else if (variant == 2)
-            hipLaunchKernelGGL((k_preprocess_f32<64, 64, 256, 7, 4>), grid, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
-        else {
-            dim3 grid32((W + 63) / 64, (H + 31) / 32, n);
-            hipLaunchKernelGGL((k_preprocess_f32<64, 32, 256, 4, 2>), grid32, dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
         }
     }
     SV_LAUNCH_CHECK("k_preprocess");

@@ -1,6 +1,6 @@
 // K3 -- DigitCNN.forward (ml/model.py:34-42, eval mode) on MI355X, fp32 throughout.
 //
-//   k_conv_features : persistent; one workgroup (4 waves) per PAIR of cells.
+//   k_conv_features_pc : persistent, one 512-thread workgroup per CU working through PAIRS of cells.
 //        conv1 (1->32, 3x3, pad 1) + ReLU + 2x2 max-pool on the VALU into zero-bordered 16x16
 //        planes in LDS; conv2 (32->64) as an implicit GEMM on v_mfma_f32_16x16x4_f32:
 //        M = 4 pooling windows x 4 positions, N = 16 output channels, K = 4 input channels of one
@@ -9,14 +9,14 @@
 //        144 VGPRs for the life of the kernel.  The 16x16 accumulator holds the 4 positions of a
 //        pooling window in the 4 registers of one lane, so bias + ReLU + max-pool are 3 v_max and
 //        never leave the lane.  Output: features [cell][window 49][oc 64] f32.
-//   k_fc_head       : fc1 (3136->128) on the same MFMA with cells as M, + ReLU, fc2 (128->10),
-//        argmax (pipeline/run.py:142) and softmax[argmax] (run.py:141-143).
+//   k_fc_head       : fc1 (3136->128) on the same MFMA with cells as M (explicit two-deep register pipeline
+//        for the weight/feature loads), + ReLU, fc2 (128->10), argmax (pipeline/run.py:142) and
+//        softmax[argmax] (run.py:141-143).
 //
 // Weight images are packed on the host by sv_load_weights_f32 (sv_api.cpp) into exactly the
 // per-lane register order the kernels load.
 #include "sv_device.h"
 #include "sv_internal.h"
-#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,114 +34,9 @@ __device__ __forceinline__ float glue_norm(u8 c)
     return __fdiv_rn(__fsub_rn(t, 0.5f), 0.5f);
 }
 
-template <bool U8IN>
-__global__ __launch_bounds__(256, 2) void k_conv_features(const void *__restrict__ xin, long B,
-                                                          const float *__restrict__ w1, const float *__restrict__ b1,
-                                                          const float *__restrict__ w2reg, const float *__restrict__ b2,
-                                                          float *__restrict__ feat)
-{
-    __shared__ __attribute__((aligned(16))) float lds[2 * IN_CELL + 2 * C1_CELL];  // 72,992 B -> 2 workgroups per CU
-    float *in_s = lds;                 // [2][900]
-    float *c1 = lds + 2 * IN_CELL;     // [2][32][257]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int np = wave >> 1, par = wave & 1;
-
-    // conv2 weights for this wave's 32 output channels: 144 VGPRs, loaded once
-    float breg[2][72];
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int ks = 0; ks < 72; ks++) breg[t][ks] = w2reg[((np * 2 + t) * 72 + ks) * 64 + lane];
-    const float bias2_0 = b2[32 * np + (lane & 15)], bias2_1 = b2[32 * np + 16 + (lane & 15)];
-
-    for (int i = tid; i < 2 * IN_CELL + 2 * C1_CELL; i += 256) lds[i] = 0.f;  // borders stay zero for good
-    __syncthreads();
-
-    const long npairs = (B + 1) / 2;
-    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
-        // ---- stage the two 28x28 inputs into the padded tiles
-        for (int i = tid; i < 2 * 784; i += 256) {
-            const int cl = i / 784, p = i - cl * 784, y = p / 28, x = p - y * 28;
-            long cg = pair * 2 + cl;
-            if (cg >= B) cg = B - 1;
-            float v;
-            if (U8IN) v = glue_norm(((const u8 *)xin)[cg * 784 + p]);
-            else v = ((const float *)xin)[cg * 784 + p];
-            in_s[cl * IN_CELL + (y + 1) * IN_W + x + 1] = v;
-        }
-        __syncthreads();
-
-        // ---- conv1 + ReLU + pool: wave w owns output channels 8w..8w+7
-        for (int rnd = 0; rnd < 7; rnd++) {
-            const int idx = rnd * 64 + lane;
-            if (idx < 392) {
-                const int cl = idx / 196, pp = idx - cl * 196, py = pp / 14, px = pp - py * 14;
-                float patch[4][4];
-                const float *src = in_s + cl * IN_CELL + (2 * py) * IN_W + 2 * px;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) patch[i][j] = src[i * IN_W + j];
-                float *dstp = c1 + cl * C1_CELL + (py + 1) * 16 + px + 1;
-#pragma unroll
-                for (int o = 0; o < 8; o++) {
-                    const int oc = wave * 8 + o;
-                    const float *w = w1 + oc * 9;
-                    const float bias = b1[oc];
-                    float m = -3.0e38f;
-#pragma unroll
-                    for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-                        for (int dx = 0; dx < 2; dx++) {
-                            float acc = bias;
-#pragma unroll
-                            for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                                for (int kx = 0; kx < 3; kx++) acc = __builtin_fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
-                            m = fmaxf(m, acc);
-                        }
-                    dstp[oc * PLANE] = fmaxf(m, 0.f);
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- conv2 on MFMA: 25 tiles of 4 pooling windows (2 cells x 49 windows = 98)
-        for (int j = par; j < 25; j += 2) {
-            const int i16 = lane & 15, q = lane >> 4;
-            int g = 4 * j + (i16 >> 2);
-            if (g > 97) g = 97;
-            const int cl = g >= 49 ? 1 : 0, wl = g - 49 * cl, wy = wl / 7, wx = wl - 7 * wy, s = i16 & 3;
-            const float *ap = c1 + cl * C1_CELL + q * 8 * PLANE + (2 * wy + (s >> 1)) * 16 + 2 * wx + (s & 1);
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 72; ks++) {
-                const int tap = ks >> 3, icb = ks & 7;
-                const float a = ap[icb * PLANE + (tap / 3) * 16 + (tap % 3)];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[0][ks], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[1][ks], acc1, 0, 0, 0);
-            }
-            // rows 4q..4q+3 of the tile = the 4 positions of window 4j+q; column = lane&15
-            const int gw = 4 * j + q;
-            if (gw < 98) {
-                const int ocl = gw >= 49 ? 1 : 0, owl = gw - 49 * ocl;
-                const long cg = pair * 2 + ocl;
-                if (cg < B) {
-                    float *o = feat + cg * FEAT + owl * 64 + 32 * np + i16;
-                    o[0] = fmaxf(fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc0[2], acc0[3])) + bias2_0, 0.f);
-                    o[16] = fmaxf(fmaxf(fmaxf(acc1[0], acc1[1]), fmaxf(acc1[2], acc1[3])) + bias2_1, 0.f);
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// Producer/consumer form of the same kernel: one 512-thread workgroup per CU, software-pipelined over
-// cell pairs with ONE barrier per pair.
+// k_conv_features_pc: one 512-thread workgroup per CU, software-pipelined over cell pairs with ONE
+// barrier per pair (producer/consumer wave specialisation).
 //   waves 0-3 (consumers): conv2 of pair i on the MFMA pipe, from c1[i & 1]           (weights in VGPRs)
 //   waves 4-7 (producers): conv1 of pair i+1 on the VALU into c1[(i+1) & 1], and the 28x28 inputs of
 //                          pair i+2 into in_s[i & 1]
@@ -301,16 +196,30 @@ __global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat,
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-    for (int c = 0; c < 196; c++) {
-        const f32x4 a = ap[c * 4];
-        f32x4 b[8];
+    // explicit two-deep register pipeline: the 9 loads of chunk c+2 are issued before the MFMAs of chunk c
+    f32x4 a0 = ap[0], a1 = ap[4], wb0[8], wb1[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) b[t] = bp[(c * 8 + t) * 64];
+    for (int t = 0; t < 8; t++) { wb0[t] = bp[t * 64]; wb1[t] = bp[(8 + t) * 64]; }
+    for (int c = 0; c < 196; c += 2) {
+        f32x4 na0 = a0, na1 = a1, nwb0[8], nwb1[8];
+        const int c2 = c + 2 < 196 ? c + 2 : c, c3 = c + 3 < 196 ? c + 3 : c + 1;   // (tail: harmless re-loads)
+        na0 = ap[c2 * 4];
+#pragma unroll
+        for (int t = 0; t < 8; t++) nwb0[t] = bp[(c2 * 8 + t) * 64];
 #pragma unroll
         for (int e = 0; e < 4; e++)
 #pragma unroll
-            for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[t][e], acc[t], 0, 0, 0);
+            for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], wb0[t][e], acc[t], 0, 0, 0);
+        na1 = ap[c3 * 4];
+#pragma unroll
+        for (int t = 0; t < 8; t++) nwb1[t] = bp[(c3 * 8 + t) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wb1[t][e], acc[t], 0, 0, 0);
+        a0 = na0; a1 = na1;
+#pragma unroll
+        for (int t = 0; t < 8; t++) { wb0[t] = nwb0[t]; wb1[t] = nwb1[t]; }
     }
 
     // acc[t][reg]: cell row 4q+reg, hidden unit 16t + r
@@ -353,21 +262,13 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *log
 {
     const sv_weights &w = ctx->w;
     const long npairs = (B + 1) / 2;
-    const int grid = (int)(npairs < 2L * ctx->num_cus ? npairs : 2L * ctx->num_cus);
-    static const int conv_variant = getenv("SV_CONV_VARIANT") ? atoi(getenv("SV_CONV_VARIANT")) : 1;   // tuning aid
-    if (conv_variant == 1) {
+    {
         const int grid_pc = (int)(npairs < (long)ctx->num_cus ? npairs : (long)ctx->num_cus);
         sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
         if (x_is_u8)
             hipLaunchKernelGGL(k_conv_features_pc<true>, dim3(grid_pc), dim3(512), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
         else
             hipLaunchKernelGGL(k_conv_features_pc<false>, dim3(grid_pc), dim3(512), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
-    } else {
-    sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
-    if (x_is_u8)
-        hipLaunchKernelGGL(k_conv_features<true>, dim3(grid), dim3(256), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
-    else
-        hipLaunchKernelGGL(k_conv_features<false>, dim3(grid), dim3(256), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
     }
     SV_LAUNCH_CHECK("k_conv_features");
     sv_time_scope ts(ctx, SVK_FC_HEAD, s);

@@ -158,9 +158,20 @@ int sv_cnn_forward_f32(sv_ctx *ctx, const float *x /*dev*/, long B, float *logit
                        uint8_t *digits /*dev, B, or NULL*/, float *conf /*dev, B, or NULL*/,
                        void *stream);
 
-/* The same on 8-bit cells with the reference glue's tensorisation fused in:
- * x = ((255 - cell)/255 - 0.5)/0.5, pipeline/run.py:126-135 (without preprocess_cell, row N1). */
-int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*784*/, long B,
+/* The glue pipeline/run.py:122-136 puts between extract_cells and the model, fused into the CNN's input stage. */
+typedef enum sv_glue {
+    SV_GLUE_NORMALIZE = 0,  /* x = ((255 - cell)/255 - 0.5)/0.5                      (run.py:126-135 without preprocess_cell) */
+    SV_GLUE_RUNPY = 1       /* preprocess_cell first: CLAHE(2.0,(4,4)) + adaptiveThreshold(GAUSSIAN_C, BINARY, 11, 2),
+                               run.py:73-95, then the same invert + normalise -- exactly what run.py feeds the model */
+} sv_glue;
+
+/* preprocess_cell(), pipeline/run.py:73-95, on B 28x28 gray cells: CLAHE(2.0,(4,4)) then
+ * adaptiveThreshold(GAUSSIAN_C, THRESH_BINARY, 11, 2).  out: u8 {0,255}, B*784. */
+int sv_preprocess_cells_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*784*/, long B,
+                           uint8_t *out /*dev, B*784*/, void *stream);
+
+/* DigitCNN.forward on 8-bit cells with the glue fused in. */
+int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*784*/, long B, int glue,
                             float *logits /*dev*/, uint8_t *digits /*dev or NULL*/,
                             float *conf /*dev or NULL*/, void *stream);
 
@@ -169,7 +180,7 @@ int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*784*/, lo
 /* frames + homographies -> 81 digits per frame: K2 then K3 on `stream`, no host sync.
  * cells may be NULL (then context scratch is used). */
 int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames /*dev*/, int n, int H, int W,
-                        ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv /*dev, n*9*/,
+                        ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv /*dev, n*9*/, int glue,
                         uint8_t *cells /*dev n*81*784 or NULL*/, float *logits /*dev, n*81*10*/,
                         uint8_t *digits /*dev, n*81*/, float *conf /*dev n*81 or NULL*/, void *stream);
 

@@ -787,3 +787,85 @@ int svo_find_grid_contour(const u8 *bin, int H, int W, long pitch, double min_ar
     free(sizes);
     return found;
 }
+
+/* ================================================================================================
+ * N1  preprocess_cell() -- reference pipeline/run.py:73-95 (also ml/datasets.py:18-46):
+ *     cv2.createCLAHE(clipLimit=2.0, tileGridSize=(4,4)).apply(cell)  then
+ *     cv2.adaptiveThreshold(.., GAUSSIAN_C, THRESH_BINARY, 11, 2).
+ *  CLAHE as OpenCV's CLAHE_Impl does it for 8-bit images whose size divides by the tile grid:
+ *  per tile: 256-bin histogram; clip at max(1, int(clip*tileArea/256)); clipped mass spread evenly
+ *  (batch + one extra every 256/residual bins); LUT[i] = round_half_even(cumsum[i] * (255.f/tileArea));
+ *  per pixel: bilinear blend of the four neighbouring tiles' LUT values with weights from
+ *  (x/tile_w - 0.5), (y/tile_h - 0.5) in float32, one rounding per operation (clahe.cpp is built with
+ *  the baseline instruction set: no FMA on x86-64), round_half_even, saturate.  PARITY UNPINNED.
+ * ============================================================================================== */
+int svo_clahe_u8(const u8 *src, int H, int W, double clip, int tiles_x, int tiles_y, u8 *dst)
+{
+    if (tiles_x <= 0 || tiles_y <= 0 || W % tiles_x || H % tiles_y) return -1; /* padded case not restated */
+    const int tw = W / tiles_x, th = H / tiles_y, area = tw * th;
+    const float lut_scale = 255.0f / (float)area;
+    int clip_limit = 0;
+    if (clip > 0.0) {
+        clip_limit = (int)(clip * area / 256);
+        if (clip_limit < 1) clip_limit = 1;
+    }
+    u8 *lut = (u8 *)malloc((size_t)tiles_x * tiles_y * 256);
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            int hist[256] = {0};
+            for (int y = 0; y < th; y++)
+                for (int x = 0; x < tw; x++) hist[src[(long)(ty * th + y) * W + tx * tw + x]]++;
+            if (clip_limit > 0) {
+                int clipped = 0;
+                for (int i = 0; i < 256; i++)
+                    if (hist[i] > clip_limit) { clipped += hist[i] - clip_limit; hist[i] = clip_limit; }
+                int batch = clipped / 256, residual = clipped - batch * 256;
+                for (int i = 0; i < 256; i++) hist[i] += batch;
+                if (residual != 0) {
+                    int step = 256 / residual > 1 ? 256 / residual : 1;
+                    for (int i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++;
+                }
+            }
+            int sum = 0;
+            u8 *l = lut + (size_t)(ty * tiles_x + tx) * 256;
+            for (int i = 0; i < 256; i++) {
+                sum += hist[i];
+                long v = lrintf((float)sum * lut_scale);
+                l[i] = (u8)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    for (int y = 0; y < H; y++) {
+        float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+        float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > tiles_y - 1) ty2 = tiles_y - 1;
+        for (int x = 0; x < W; x++) {
+            float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+            float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > tiles_x - 1) tx2 = tiles_x - 1;
+            int v = src[(long)y * W + x];
+            float l11 = lut[(size_t)(ty1 * tiles_x + tx1) * 256 + v], l12 = lut[(size_t)(ty1 * tiles_x + tx2) * 256 + v];
+            float l21 = lut[(size_t)(ty2 * tiles_x + tx1) * 256 + v], l22 = lut[(size_t)(ty2 * tiles_x + tx2) * 256 + v];
+            float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+            long r = lrintf(res);
+            dst[(long)y * W + x] = (u8)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+    free(lut);
+    return 0;
+}
+
+/* preprocess_cell on n 28x28 cells (already gray, already 28x28: what extract_cells returns). */
+int svo_preprocess_cells(const u8 *cells, long n, u8 *out)
+{
+    u8 tmp[784];
+    for (long i = 0; i < n; i++) {
+        if (svo_clahe_u8(cells + i * 784, 28, 28, 2.0, 4, 4, tmp) != 0) return -1;
+        if (svo_adaptive_threshold_u8(tmp, 28, 28, 11, 2.0, 0, out + i * 784) != 0) return -1;
+    }
+    return 0;
+}

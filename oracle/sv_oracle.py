@@ -228,3 +228,21 @@ def find_grid_contour(binary, min_area_ratio=0.1, epsilon_ratio=0.02):
     found = lib().svo_find_grid_contour(p, H, W, C.c_long(W), C.c_double(min_area_ratio), C.c_double(epsilon_ratio),
                                         corners.ctypes.data_as(C.c_void_p))
     return corners if found else None
+
+
+# ---- N1: per-cell glue of pipeline/run.py:73-95 ------------------------------------------------------
+def clahe(img, clip_limit=2.0, tiles=(4, 4)):
+    img, p = _u8(img)
+    H, W = img.shape
+    out = np.empty((H, W), np.uint8)
+    if lib().svo_clahe_u8(p, H, W, C.c_double(clip_limit), int(tiles[0]), int(tiles[1]), out.ctypes.data_as(C.c_void_p)) != 0:
+        raise NotImplementedError("oracle: CLAHE only for sizes divisible by the tile grid")
+    return out
+
+
+def preprocess_cells(cells):
+    """run.py's preprocess_cell on u8 [n,28,28]: CLAHE(2.0,(4,4)) then adaptiveThreshold(GAUSSIAN, BINARY, 11, 2)."""
+    cells, p = _u8(cells)
+    out = np.empty(cells.shape, np.uint8)
+    assert lib().svo_preprocess_cells(p, C.c_long(cells.size // 784), out.ctypes.data_as(C.c_void_p)) == 0
+    return out

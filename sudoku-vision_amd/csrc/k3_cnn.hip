@@ -35,6 +35,108 @@ __device__ __forceinline__ float glue_norm(u8 c)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// N1 -- the per-cell glue of pipeline/run.py:73-95 (preprocess_cell), one wave per cell (k_preprocess_cells):
+//   cv2.createCLAHE(2.0, (4,4)) on 28x28: 16 tiles of 7x7; the clip limit is max(1, int(2*49/256)) = 1, so a
+//   tile's clipped histogram is its set of present values (a 256-bit bitmap) plus the redistributed residual
+//   (one extra count every 256/residual bins); LUT[v] = rint(cumsum[v] * 255/49) is evaluated on demand from
+//   the bitmap's prefix popcounts -- no histogram or LUT arrays.  Bilinear blend of the 4 neighbouring tiles
+//   in f32 with one rounding per operation, then adaptiveThreshold(GAUSSIAN_C, BINARY, 11, 2) on the 28x28
+//   result (same f32 FMA-chain Gaussian as K1, REPLICATE border).  (Fusing this into the conv kernel's producer
+//   waves was tried: the producers share the consumers' 216-VGPR allocation and the extra code spilled.)
+// ---------------------------------------------------------------------------------------------------
+struct N1Scratch {
+    float cf[784];          // CLAHE output as f32
+    float rw[784];          // Gaussian row pass
+    unsigned bits[16][8];   // per tile: which of the 256 values occur
+    unsigned pre[16][8];    // per tile: number of present values below word w
+    int residual[16], step[16];
+};
+
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); }
+
+__device__ __forceinline__ float n1_lut(const N1Scratch &sc, int tile, int v)
+{
+    const int w = v >> 5;
+    const unsigned mask = 0xFFFFFFFFu >> (31 - (v & 31));
+    int cum = (int)sc.pre[tile][w] + __popc(sc.bits[tile][w] & mask);
+    const int res = sc.residual[tile];
+    if (res != 0) { const int extra = v / sc.step[tile] + 1; cum += extra < res ? extra : res; }
+    const float f = rintf(__fmul_rn((float)cum, 255.0f / 49.0f));
+    return fminf(fmaxf(f, 0.f), 255.f);
+}
+
+// one wave: cell (u8[784], global) -> normalised CNN input written into the zero-bordered 30x30 tile `in_dst`
+__device__ void n1_preprocess_cell(const u8 *__restrict__ cell, float *in_dst, N1Scratch &sc, int lane, const float (&taps)[11])
+{
+    int v[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) { const int i = lane + 64 * k; v[k] = i < 784 ? cell[i] : 0; }
+    for (int i = lane; i < 128; i += 64) (&sc.bits[0][0])[i] = 0;
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const int i = lane + 64 * k;
+        if (i < 784) { const int y = i / 28, x = i - 28 * y; atomicOr(&sc.bits[(y / 7) * 4 + x / 7][v[k] >> 5], 1u << (v[k] & 31)); }
+    }
+    wave_lds_fence();
+    if (lane < 16) {
+        int n = 0;
+        for (int w = 0; w < 8; w++) { sc.pre[lane][w] = n; n += __popc(sc.bits[lane][w]); }
+        const int residual = 49 - n;                 // clipped mass: every present value keeps one count
+        sc.residual[lane] = residual;
+        sc.step[lane] = residual > 0 ? (256 / residual > 1 ? 256 / residual : 1) : 1;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const int i = lane + 64 * k;
+        if (i < 784) {
+            const int y = i / 28, x = i - 28 * y;
+            const float txf = __fsub_rn(__fmul_rn((float)x, 1.0f / 7.0f), 0.5f), tyf = __fsub_rn(__fmul_rn((float)y, 1.0f / 7.0f), 0.5f);
+            int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
+            const float xa = __fsub_rn(txf, (float)tx1), ya = __fsub_rn(tyf, (float)ty1), xa1 = __fsub_rn(1.0f, xa), ya1 = __fsub_rn(1.0f, ya);
+            int tx2 = tx1 + 1, ty2 = ty1 + 1;
+            tx1 = tx1 < 0 ? 0 : tx1; ty1 = ty1 < 0 ? 0 : ty1; tx2 = tx2 > 3 ? 3 : tx2; ty2 = ty2 > 3 ? 3 : ty2;
+            const float l11 = n1_lut(sc, ty1 * 4 + tx1, v[k]), l12 = n1_lut(sc, ty1 * 4 + tx2, v[k]);
+            const float l21 = n1_lut(sc, ty2 * 4 + tx1, v[k]), l22 = n1_lut(sc, ty2 * 4 + tx2, v[k]);
+            const float top = __fadd_rn(__fmul_rn(l11, xa1), __fmul_rn(l12, xa)), bot = __fadd_rn(__fmul_rn(l21, xa1), __fmul_rn(l22, xa));
+            const float res = __fadd_rn(__fmul_rn(top, ya1), __fmul_rn(bot, ya));
+            sc.cf[i] = fminf(fmaxf(rintf(res), 0.f), 255.f);
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 13; k++) {      // Gaussian row pass, taps left to right, REPLICATE
+        const int i = lane + 64 * k;
+        if (i < 784) {
+            const int y = i / 28, x = i - 28 * y;
+            const float *row = sc.cf + 28 * y;
+            float acc = __fmul_rn(taps[0], row[x - 5 < 0 ? 0 : x - 5]);
+#pragma unroll
+            for (int j = 1; j < 11; j++) { int xx = x + j - 5; xx = xx < 0 ? 0 : (xx > 27 ? 27 : xx); acc = __builtin_fmaf(row[xx], taps[j], acc); }
+            sc.rw[i] = acc;
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 13; k++) {      // column pass (centre, then pairs), threshold BINARY, invert + normalise
+        const int i = lane + 64 * k;
+        if (i < 784) {
+            const int y = i / 28, x = i - 28 * y;
+            float acc = __fmul_rn(taps[5], sc.rw[i]);
+#pragma unroll
+            for (int j = 1; j <= 5; j++) {
+                const int yl = y + j > 27 ? 27 : y + j, yh = y - j < 0 ? 0 : y - j;
+                acc = __builtin_fmaf(__fadd_rn(sc.rw[28 * yl + x], sc.rw[28 * yh + x]), taps[5 + j], acc);
+            }
+            const float mean = fminf(fmaxf(rintf(acc), 0.f), 255.f);
+            const bool white = __fsub_rn(sc.cf[i], mean) > -2.f;     // THRESH_BINARY: src - mean > -C
+            in_dst[(y + 1) * IN_W + x + 1] = white ? -1.0f : 1.0f;   // ((255 - 255)/255 - .5)/.5 = -1 ; ((255 - 0)/255 - .5)/.5 = +1
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_conv_features_pc: one 512-thread workgroup per CU, software-pipelined over cell pairs with ONE
 // barrier per pair (producer/consumer wave specialisation).
 //   waves 0-3 (consumers): conv2 of pair i on the MFMA pipe, from c1[i & 1]           (weights in VGPRs)
@@ -43,6 +145,8 @@ __device__ __forceinline__ float glue_norm(u8 c)
 // The matrix pipe and the vector pipe of a SIMD run side by side, so the consumers never leave the
 // MFMA stream for conv1 or for input staging.  LDS: 2 x 65,792 (conv1 planes) + 2 x 7,200 (inputs) B.
 // ---------------------------------------------------------------------------------------------------
+struct GaussTaps { float k[11]; };
+
 template <bool U8IN>
 __global__ __launch_bounds__(512, 2) void k_conv_features_pc(const void *__restrict__ xin, long B,
                                                              const float *__restrict__ w1, const float *__restrict__ b1,
@@ -256,12 +360,42 @@ __global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat,
     }
 }
 
+// preprocess_cell (pipeline/run.py:73-95) as a stand-alone call: one wave per cell, u8 in -> u8 {0,255} out
+__global__ __launch_bounds__(256) void k_preprocess_cells(const u8 *__restrict__ cells, long B, GaussTaps taps, u8 *__restrict__ out)
+{
+    __shared__ N1Scratch sc[4];
+    __shared__ float tile[4][IN_CELL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * 4 + wave;
+    if (c >= B) return;
+    n1_preprocess_cell(cells + c * 784, tile[wave], sc[wave], lane, taps.k);
+    wave_lds_fence();
+    for (int i = lane; i < 784; i += 64) {
+        const int y = i / 28, x = i - 28 * y;
+        out[c * 784 + i] = tile[wave][(y + 1) * IN_W + x + 1] < 0.f ? 255 : 0;
+    }
+}
+
 }  // namespace
 
-int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
+int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s)
+{
+    GaussTaps taps;
+    sv_gaussian_taps_f32(11, taps.k);
+    hipLaunchKernelGGL(k_preprocess_cells, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, cells, B, taps, out);
+    SV_LAUNCH_CHECK("k_preprocess_cells");
+    return SV_OK;
+}
+
+int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
 {
     const sv_weights &w = ctx->w;
     const long npairs = (B + 1) / 2;
+    if (x_is_u8 && glue == SV_GLUE_RUNPY) {      // run.py's preprocess_cell as its own pass; its {0,255} output then takes the plain glue
+        int rc = svk_preprocess_cells((const u8 *)x, B, ctx->cells2, s);
+        if (rc) return rc;
+        x = ctx->cells2;
+    }
     {
         const int grid_pc = (int)(npairs < (long)ctx->num_cus ? npairs : (long)ctx->num_cus);
         sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);

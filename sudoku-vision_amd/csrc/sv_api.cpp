@@ -56,6 +56,7 @@ extern "C" int sv_ctx_destroy(sv_ctx *ctx)
     free_weights(ctx->w);
     if (ctx->features) (void)hipFree(ctx->features);
     if (ctx->cells) (void)hipFree(ctx->cells);
+    if (ctx->cells2) (void)hipFree(ctx->cells2);
     for (auto &t : ctx->timeline) { (void)hipEventDestroy(t.t0); (void)hipEventDestroy(t.t1); }
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -68,11 +69,14 @@ int sv_ensure_scratch(sv_ctx *ctx, long cells)
     SV_HIP(hipSetDevice(ctx->device));
     if (ctx->features) SV_HIP(hipFree(ctx->features));
     if (ctx->cells) SV_HIP(hipFree(ctx->cells));
+    if (ctx->cells2) SV_HIP(hipFree(ctx->cells2));
     ctx->features = nullptr;
     ctx->cells = nullptr;
+    ctx->cells2 = nullptr;
     ctx->cap_cells = 0;
     SV_HIP(hipMalloc((void **)&ctx->features, sizeof(float) * 3136 * (size_t)cells));
     SV_HIP(hipMalloc((void **)&ctx->cells, (size_t)SV_CELL_PX * (size_t)cells));
+    SV_HIP(hipMalloc((void **)&ctx->cells2, (size_t)SV_CELL_PX * (size_t)cells));
     ctx->cap_cells = cells;
     return SV_OK;
 }
@@ -364,27 +368,35 @@ extern "C" int sv_warp_cells_u8(sv_ctx *ctx, const uint8_t *frames, int n, int H
     return svk_warp_cells(ctx, frames, n, H, W, pitch, frame_stride, minv, cells, S(stream));
 }
 
-static int cnn_common(sv_ctx *ctx, const void *x, bool u8in, long B, float *logits, uint8_t *digits, float *conf, void *stream)
+static int cnn_common(sv_ctx *ctx, const void *x, bool u8in, int glue, long B, float *logits, uint8_t *digits, float *conf, void *stream)
 {
     if (!ctx || !x || !logits) return sv_fail(SV_ERR_BAD_ARG, "sv_cnn_forward: NULL argument");
     if (B <= 0) return sv_fail(SV_ERR_BAD_ARG, "sv_cnn_forward: B = %ld", B);
     if (!ctx->w.loaded) return sv_fail(SV_ERR_NO_WEIGHTS, "sv_cnn_forward: call sv_load_weights_f32 first");
     int rc = sv_ensure_scratch(ctx, B);
     if (rc) return rc;
-    return svk_cnn_forward(ctx, x, u8in, B, logits, digits, conf, S(stream));
+    if (glue != SV_GLUE_NORMALIZE && glue != SV_GLUE_RUNPY) return sv_fail(SV_ERR_BAD_ARG, "sv_cnn_forward: glue %d", glue);
+    return svk_cnn_forward(ctx, x, u8in, glue, B, logits, digits, conf, S(stream));
 }
 
 extern "C" int sv_cnn_forward_f32(sv_ctx *ctx, const float *x, long B, float *logits, uint8_t *digits, float *conf, void *stream)
 {
-    return cnn_common(ctx, x, false, B, logits, digits, conf, stream);
+    return cnn_common(ctx, x, false, SV_GLUE_NORMALIZE, B, logits, digits, conf, stream);
 }
 
-extern "C" int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells, long B, float *logits, uint8_t *digits, float *conf, void *stream)
+extern "C" int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells, long B, int glue, float *logits, uint8_t *digits, float *conf, void *stream)
 {
-    return cnn_common(ctx, cells, true, B, logits, digits, conf, stream);
+    return cnn_common(ctx, cells, true, glue, B, logits, digits, conf, stream);
 }
 
-extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, uint8_t *cells, float *logits, uint8_t *digits, float *conf, void *stream)
+extern "C" int sv_preprocess_cells_u8(sv_ctx *ctx, const uint8_t *cells, long B, uint8_t *out, void *stream)
+{
+    REQUIRE(ctx && cells && out, "NULL argument");
+    REQUIRE(B > 0, "B must be positive");
+    return svk_preprocess_cells(cells, B, out, S(stream));
+}
+
+extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, int glue, uint8_t *cells, float *logits, uint8_t *digits, float *conf, void *stream)
 {
     REQUIRE(ctx && frames && minv && logits && digits, "NULL argument");
     REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
@@ -394,5 +406,6 @@ extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, in
     if (rc) return rc;
     uint8_t *c = cells ? cells : ctx->cells;
     if ((rc = svk_warp_cells(ctx, frames, n, H, W, pitch, frame_stride, minv, c, S(stream)))) return rc;
-    return svk_cnn_forward(ctx, c, true, B, logits, digits, conf, S(stream));
+    if (glue != SV_GLUE_NORMALIZE && glue != SV_GLUE_RUNPY) return sv_fail(SV_ERR_BAD_ARG, "sv_frames_to_digits: glue %d", glue);
+    return svk_cnn_forward(ctx, c, true, glue, B, logits, digits, conf, S(stream));
 }

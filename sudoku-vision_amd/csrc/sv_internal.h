@@ -30,6 +30,7 @@ struct sv_ctx {
     // grow-only scratch
     float *features = nullptr;  // [cells][49][64] pooled conv2 output
     u8 *cells = nullptr;        // [cells][784]
+    u8 *cells2 = nullptr;       // [cells][784] preprocess_cell output (SV_GLUE_RUNPY)
     long cap_cells = 0;
     // optional per-kernel timing (sv_timing_begin/sv_timing_end): hipEvents on the launch stream
     bool timing = false;
@@ -75,8 +76,10 @@ int svk_extract_cells(const u8 *grid, int h, int w, ptrdiff_t pitch, int channel
                       int margin_w, u8 *cells, hipStream_t s);
 int svk_warp_cells(sv_ctx *ctx, const u8 *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv,
                    u8 *cells, hipStream_t s);
-int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf,
+int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, float *logits, u8 *digits, float *conf,
                     hipStream_t s);
+
+int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s);
 
 // host helpers
 void sv_gaussian_taps_f32(int n, float *out);

@@ -5,7 +5,8 @@ software-pipelined for a resident pool of frames:
     GPU  K1 (binary)  --D2H, pinned-->  CPU contour corner search (threads)  --Minv, H2D-->  GPU  K2 -> K3
 
 Chunks of frames are double-buffered: while the host searches chunk i, the GPU thresholds chunk i+1 and
-classifies chunk i-1.  A frame whose grid is not found gets found=False and digits 0 (the reference
+classifies chunk i-1.  `glue` selects what sits between extract_cells and the model (see include/sudoku_vision_hip.h sv_glue).
+A frame whose grid is not found gets found=False and digits 0 (the reference
 returns "Grid detection failed" for it, pipeline/run.py:268-272)."""
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -18,10 +19,11 @@ from .runtime import Context
 
 
 class FramePipeline:
-    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1):
+    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1, glue=0):
         self.ctx, self.H, self.W, self.chunk = ctx, H, W, chunk
         self.host_threads = host_threads or max(1, (os.cpu_count() or 2) - 1)
         self.min_area_ratio = min_area_ratio
+        self.glue = glue            # Context.GLUE_NORMALIZE, or GLUE_RUNPY for run.py's preprocess_cell (CLAHE + threshold)
         dev = ctx.device
         self.s_pre = torch.cuda.Stream(dev)       # K1 + D2H
         self.s_cls = torch.cuda.Stream(dev)       # H2D + K2 + K3
@@ -65,7 +67,7 @@ class FramePipeline:
             with torch.cuda.stream(self.s_cls):
                 self.minv_dev[slot][:m].copy_(self.minv_pin[slot][:m], non_blocking=True)
                 sub = {k: out[k][s:s + m] for k in ("logits", "digits", "conf")}
-                self.ctx.frames_to_digits(frames[s:s + m], self.minv_dev[slot][:m], out=sub)
+                self.ctx.frames_to_digits(frames[s:s + m], self.minv_dev[slot][:m], out=sub, glue=self.glue)
                 if not found.all():
                     out["digits"][s:s + m][torch.from_numpy(~found).to(dev)] = 0
                 ev = torch.cuda.Event()
@@ -92,9 +94,9 @@ class FramePipeline:
         return out
 
 
-def recognize_image(image, model_state_dict=None, ctx=None):
+def recognize_image(image, model_state_dict=None, ctx=None, glue=Context.GLUE_RUNPY):
     """One BGR image (numpy uint8 [H,W,3]) -> dict(grid 9x9 list, digits, confidences, corners) or None when no
-    grid is found -- the call order of pipeline/run.py:261-312 with preprocess_cell (CLAHE, row N1) left out."""
+    grid is found -- the call order of pipeline/run.py:261-312, preprocess_cell (:73-95) included by default."""
     from .runtime import default_context
     ctx = ctx or default_context()
     if model_state_dict is not None:
@@ -105,7 +107,7 @@ def recognize_image(image, model_state_dict=None, ctx=None):
     if corners is None:
         return None
     minv = ctx.minv_to_device(Context.corners_to_minv(corners[None].astype(np.float32)))
-    out = ctx.frames_to_digits(frames, minv)
+    out = ctx.frames_to_digits(frames, minv, glue=glue)
     digits = out["digits"][0].cpu().numpy()
     return {"grid": [[int(digits[r * 9 + c]) for c in range(9)] for r in range(9)], "digits": digits,
             "confidence": out["conf"][0].cpu().numpy(), "logits": out["logits"][0].cpu().numpy(), "corners": corners}

@@ -143,19 +143,31 @@ class Context:
         return out
 
     # ---- K3 -----------------------------------------------------------------------------------
-    def cnn_forward(self, x, want_digits=False):
-        """x f32 [B,1,28,28] or u8 [B,28,28] cells (glue tensorisation fused) -> logits [B,10] (, digits, conf)."""
+    GLUE_NORMALIZE, GLUE_RUNPY = 0, 1
+
+    def preprocess_cells(self, cells):
+        """run.py's preprocess_cell on u8 cells [B,28,28] -> u8 {0,255} [B,28,28]."""
+        out = torch.empty_like(cells)
+        _native.check(_native.lib().sv_preprocess_cells_u8(self._h, _ptr(cells), cells.shape[0], _ptr(out), _stream_ptr()), "sv_preprocess_cells_u8")
+        return out
+
+    def cnn_forward(self, x, want_digits=False, glue=0):
+        """x f32 [B,1,28,28], or u8 [B,28,28] cells with the run.py glue fused in (glue=GLUE_NORMALIZE: invert+normalise;
+        GLUE_RUNPY: preprocess_cell (CLAHE + adaptive threshold) first) -> logits [B,10] (, digits, conf)."""
         B = x.shape[0]
         logits = torch.empty((B, 10), dtype=torch.float32, device=self.device)
         digits = torch.empty((B,), dtype=torch.uint8, device=self.device) if want_digits else None
         conf = torch.empty((B,), dtype=torch.float32, device=self.device) if want_digits else None
-        fn = _native.lib().sv_cnn_forward_cells_u8 if x.dtype == torch.uint8 else _native.lib().sv_cnn_forward_f32
-        _native.check(fn(self._h, _ptr(x), B, _ptr(logits), _ptr(digits) if want_digits else None, _ptr(conf) if want_digits else None,
-                         _stream_ptr()), "sv_cnn_forward")
+        dg, cf = (_ptr(digits) if want_digits else None), (_ptr(conf) if want_digits else None)
+        if x.dtype == torch.uint8:
+            rc = _native.lib().sv_cnn_forward_cells_u8(self._h, _ptr(x), B, int(glue), _ptr(logits), dg, cf, _stream_ptr())
+        else:
+            rc = _native.lib().sv_cnn_forward_f32(self._h, _ptr(x), B, _ptr(logits), dg, cf, _stream_ptr())
+        _native.check(rc, "sv_cnn_forward")
         return (logits, digits, conf) if want_digits else logits
 
     # ---- whole path ---------------------------------------------------------------------------
-    def frames_to_digits(self, frames, minv_dev, out=None, keep_cells=False):
+    def frames_to_digits(self, frames, minv_dev, out=None, keep_cells=False, glue=0):
         """frames u8 [n,H,W,3], minv_dev f64 [n,3,3] on device -> dict(logits [n,81,10], digits [n,81], conf [n,81])."""
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
         if out is None:
@@ -165,7 +177,7 @@ class Context:
             if keep_cells:
                 out["cells"] = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device)
         cells = out.get("cells")
-        _native.check(_native.lib().sv_frames_to_digits(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(minv_dev),
+        _native.check(_native.lib().sv_frames_to_digits(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(minv_dev), int(glue),
                                                         _ptr(cells) if cells is not None else None, _ptr(out["logits"]), _ptr(out["digits"]),
                                                         _ptr(out["conf"]), _stream_ptr()), "sv_frames_to_digits")
         return out

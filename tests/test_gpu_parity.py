@@ -214,6 +214,31 @@ def test_pipeline_with_host_corner_search(ctx, golden_dir):
         el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(cells)[:, None])
         assert np.abs(out["logits"][i].cpu().numpy() - el.numpy()).max() <= LOGIT_TOL
         assert (out["digits"][i].cpu().numpy() == ed.numpy()).all()
-    one = recognize_image(host[0], ctx=ctx)
+    one = recognize_image(host[0], ctx=ctx, glue=ctx.GLUE_NORMALIZE)
     assert (one["digits"] == out["digits"][0].cpu().numpy()).all() and len(one["grid"]) == 9
+    # run.py's own glue (preprocess_cell) end to end
+    c0 = o.find_grid_contour(o.preprocess_for_grid_detection(host[0]))
+    proc = o.preprocess_cells(o.warp_cells(host[0], c0.astype(np.float32)))
+    ed = cnn_oracle.predict(sd, o.cells_to_input(proc)[:, None])[1].numpy()
+    assert (recognize_image(host[0], ctx=ctx)["digits"] == ed).all()
     assert recognize_image(host[3], ctx=ctx) is None
+
+
+def test_preprocess_cells_and_runpy_glue(ctx, golden_dir):
+    """N1: run.py's preprocess_cell (CLAHE + adaptive threshold) on the GPU, bit-exact; and the CNN fed through it."""
+    rs = np.random.RandomState(17)
+    frames, corners, _ = _frames(2, 540, 960, seed=41)
+    real = np.concatenate([o.warp_cells(f, c) for f, c in zip(frames.cpu().numpy(), corners)])
+    cells = np.concatenate([real, rs.randint(0, 256, (30, 28, 28)).astype(np.uint8), np.full((2, 28, 28), 200, np.uint8),
+                            rs.randint(90, 110, (7, 28, 28)).astype(np.uint8)])
+    d = torch.from_numpy(cells).cuda()
+    got = ctx.preprocess_cells(d).cpu().numpy()
+    exp = o.preprocess_cells(cells)
+    assert (got == exp).all()
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    ctx.load_state_dict(sd)
+    logits, digits, conf = ctx.cnn_forward(d, want_digits=True, glue=ctx.GLUE_RUNPY)
+    el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(exp)[:, None])
+    assert np.abs(logits.cpu().numpy() - el.numpy()).max() <= LOGIT_TOL
+    assert (digits.cpu().numpy() == ed.numpy()).all()

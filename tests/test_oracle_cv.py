@@ -177,3 +177,59 @@ def test_glue_tensorisation():
     x = o.cells_to_input(c)
     ref = ((255 - c).astype(np.float32) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5)
     assert (x == ref).all() and x[0] == 1.0 and x[255] == -1.0
+
+
+# ---- N1: preprocess_cell (pipeline/run.py:73-95) ------------------------------------------------------
+def _clahe_numpy(img, clip=2.0, tiles=(4, 4)):
+    """Independent re-derivation of CLAHE (vectorised numpy, float64 blending) for cross-checking the C oracle."""
+    H, W = img.shape
+    tx_n, ty_n = tiles
+    tw, th = W // tx_n, H // ty_n
+    area = tw * th
+    limit = max(int(clip * area / 256), 1)
+    luts = np.zeros((ty_n, tx_n, 256))
+    for ty in range(ty_n):
+        for tx in range(tx_n):
+            hist = np.bincount(img[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].ravel(), minlength=256)
+            clipped = np.maximum(hist - limit, 0).sum()
+            hist = np.minimum(hist, limit) + clipped // 256
+            res = clipped % 256
+            if res:
+                step = max(256 // res, 1)
+                idx = np.arange(0, 256, step)[:res]
+                hist[idx] += 1
+            luts[ty, tx] = np.clip(np.rint(np.cumsum(hist) * np.float32(255.0 / area)), 0, 255)
+    ys, xs = np.mgrid[0:H, 0:W]
+    fx, fy = xs / tw - 0.5, ys / th - 0.5
+    x1, y1 = np.floor(fx).astype(int), np.floor(fy).astype(int)
+    xa, ya = fx - x1, fy - y1
+    x2, y2 = np.minimum(x1 + 1, tx_n - 1), np.minimum(y1 + 1, ty_n - 1)
+    x1, y1 = np.maximum(x1, 0), np.maximum(y1, 0)
+    v = img
+    res = (luts[y1, x1, v] * (1 - xa) + luts[y1, x2, v] * xa) * (1 - ya) + (luts[y2, x1, v] * (1 - xa) + luts[y2, x2, v] * xa) * ya
+    return res
+
+
+def test_clahe_matches_independent_numpy():
+    rs = np.random.RandomState(11)
+    for kind in range(4):
+        img = [rs.randint(0, 256, (28, 28)), rs.randint(100, 140, (28, 28)), np.full((28, 28), 77), _img(12, 28, 28)][kind].astype(np.uint8)
+        got = o.clahe(img).astype(np.float64)
+        ref = _clahe_numpy(img)
+        assert np.abs(got - np.rint(ref)).max() <= 1          # float32 vs float64 blending: at most a rounding tie
+        assert (got != np.rint(ref)).mean() < 0.02
+    big = rs.randint(0, 256, (64, 96)).astype(np.uint8)          # other sizes / grids / clip limits
+    assert np.abs(o.clahe(big, 4.0, (8, 4)).astype(float) - np.rint(_clahe_numpy(big, 4.0, (8, 4)))).max() <= 1
+    with pytest.raises(NotImplementedError):
+        o.clahe(np.zeros((30, 30), np.uint8))                    # not divisible by the grid: cv2 pads, not restated
+
+
+def test_preprocess_cells_definition():
+    rs = np.random.RandomState(13)
+    cells = rs.randint(0, 256, (5, 28, 28)).astype(np.uint8)
+    got = o.preprocess_cells(cells)
+    assert set(np.unique(got)) <= {0, 255}
+    for i in range(5):
+        assert (got[i] == o.adaptive_threshold(o.clahe(cells[i]), 11, 2, inv=False)).all()
+    x = o.cells_to_input(got)
+    assert set(np.unique(x)) <= {-1.0, 1.0} and ((x == -1.0) == (got == 255)).all()

@@ -165,6 +165,12 @@ typedef enum sv_glue {
                                run.py:73-95, then the same invert + normalise -- exactly what run.py feeds the model */
 } sv_glue;
 
+/* is_cell_empty(), cv/extract.py:59-79, batched: per cell the Otsu threshold (cv2.threshold THRESH_OTSU) and
+ * ratio = countNonZero(BINARY_INV image) / pixels; the caller compares ratio < threshold (default 0.02).
+ * cells: B images of cell_px pixels each.  otsu may be NULL. */
+int sv_cell_ink_ratio_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*cell_px*/, long B, int cell_px,
+                         float *ratio /*dev, B*/, int *otsu /*dev, B, or NULL*/, void *stream);
+
 /* preprocess_cell(), pipeline/run.py:73-95, on B 28x28 gray cells: CLAHE(2.0,(4,4)) then
  * adaptiveThreshold(GAUSSIAN_C, THRESH_BINARY, 11, 2).  out: u8 {0,255}, B*784. */
 int sv_preprocess_cells_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*784*/, long B,

@@ -869,3 +869,37 @@ int svo_preprocess_cells(const u8 *cells, long n, u8 *out)
     }
     return 0;
 }
+
+/* ================================================================================================
+ * N3  is_cell_empty() -- reference cv/extract.py:59-79:
+ *     cv2.threshold(cell, 0, 255, THRESH_BINARY_INV + THRESH_OTSU); countNonZero / total < threshold.
+ *  Otsu as OpenCV's getThreshVal_Otsu_8u: one pass over the 256-bin histogram in double, in this
+ *  operation order; BINARY_INV marks pixels <= threshold.  Returns the ink ratio; *otsu = threshold.
+ *  PARITY UNPINNED.
+ * ============================================================================================== */
+double svo_cell_ink_ratio(const u8 *cell, int H, int W, int *otsu)
+{
+    int h[256] = {0};
+    const long total = (long)H * W;
+    for (long i = 0; i < total; i++) h[cell[i]]++;
+    double mu = 0, scale = 1. / (double)total;
+    for (int i = 0; i < 256; i++) mu += i * (double)h[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        double p_i = h[i] * scale, q2, mu2, sigma;
+        mu1 *= q1;
+        q1 += p_i;
+        q2 = 1. - q1;
+        if ((q1 < q2 ? q1 : q2) < 1.1920928955078125e-07 || (q1 > q2 ? q1 : q2) > 1. - 1.1920928955078125e-07) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        mu2 = (mu - q1 * mu1) / q2;
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    const int t = (int)max_val;
+    long nz = 0;
+    for (long i = 0; i < total; i++) nz += cell[i] <= t;
+    if (otsu) *otsu = t;
+    return (double)nz / (double)total;
+}

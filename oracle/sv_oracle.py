@@ -246,3 +246,17 @@ def preprocess_cells(cells):
     out = np.empty(cells.shape, np.uint8)
     assert lib().svo_preprocess_cells(p, C.c_long(cells.size // 784), out.ctypes.data_as(C.c_void_p)) == 0
     return out
+
+
+# ---- N3: is_cell_empty (cv/extract.py:59-79) -----------------------------------------------------------
+def cell_ink_ratio(cell):
+    """-> (non_zero / total of the Otsu BINARY_INV image, Otsu threshold)."""
+    cell, p = _u8(cell)
+    H, W = cell.shape
+    t = C.c_int()
+    lib().svo_cell_ink_ratio.restype = C.c_double
+    return lib().svo_cell_ink_ratio(p, H, W, C.byref(t)), t.value
+
+
+def is_cell_empty(cell, threshold=0.02):
+    return cell_ink_ratio(cell)[0] < threshold

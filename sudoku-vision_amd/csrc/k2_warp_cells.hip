@@ -116,7 +116,57 @@ __global__ __launch_bounds__(256) void k_extract_cells(const u8 *__restrict__ gr
     }
 }
 
+// is_cell_empty (cv/extract.py:59-79): Otsu threshold (OpenCV's single-pass fp64 recurrence, executed by one lane
+// in the reference's operation order) of each cell, then the share of pixels <= threshold.  One wave per cell.
+__global__ __launch_bounds__(64) void k_cell_ink_ratio(const u8 *__restrict__ cells, int npx, float *__restrict__ ratio, int *__restrict__ otsu)
+{
+    __shared__ int hist[256];
+    __shared__ int thr;
+    const int lane = threadIdx.x;
+    const u8 *cell = cells + (ptrdiff_t)blockIdx.x * npx;
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < npx; i += 64) atomicAdd(&hist[cell[i]], 1);
+    __syncthreads();
+    if (lane == 0) {
+        const double scale = __ddiv_rn(1.0, (double)npx);
+        double mu = 0;
+        for (int i = 0; i < 256; i++) mu = __dadd_rn(mu, __dmul_rn((double)i, (double)hist[i]));
+        mu = __dmul_rn(mu, scale);
+        double mu1 = 0, q1 = 0, max_sigma = 0;
+        int max_val = 0;
+        for (int i = 0; i < 256; i++) {
+            const double p_i = __dmul_rn((double)hist[i], scale);
+            mu1 = __dmul_rn(mu1, q1);
+            q1 = __dadd_rn(q1, p_i);
+            const double q2 = __dsub_rn(1.0, q1);
+            if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1.0 - 1.1920928955078125e-07) continue;
+            mu1 = __ddiv_rn(__dadd_rn(mu1, __dmul_rn((double)i, p_i)), q1);
+            const double mu2 = __ddiv_rn(__dsub_rn(mu, __dmul_rn(q1, mu1)), q2);
+            const double d = __dsub_rn(mu1, mu2);
+            const double sigma = __dmul_rn(__dmul_rn(__dmul_rn(q1, q2), d), d);
+            if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+        }
+        thr = max_val;
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = lane; i < npx; i += 64) cnt += cell[i] <= thr;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane == 0) {
+        ratio[blockIdx.x] = (float)((double)cnt / (double)npx);
+        if (otsu) otsu[blockIdx.x] = thr;
+    }
+}
+
 }  // namespace
+
+int svk_cell_ink_ratio(const u8 *cells, long B, int npx, float *ratio, int *otsu, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cell_ink_ratio, dim3((unsigned)B), dim3(64), 0, s, cells, npx, ratio, otsu);
+    SV_LAUNCH_CHECK("k_cell_ink_ratio");
+    return SV_OK;
+}
 
 int svk_warp_cells(sv_ctx *ctx, const u8 *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, u8 *cells, hipStream_t s)
 {

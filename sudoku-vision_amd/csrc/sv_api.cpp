@@ -389,6 +389,13 @@ extern "C" int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells, long B
     return cnn_common(ctx, cells, true, glue, B, logits, digits, conf, stream);
 }
 
+extern "C" int sv_cell_ink_ratio_u8(sv_ctx *ctx, const uint8_t *cells, long B, int cell_px, float *ratio, int *otsu, void *stream)
+{
+    REQUIRE(ctx && cells && ratio, "NULL argument");
+    REQUIRE(B > 0 && B < 2147483647L && cell_px > 0, "bad shape");
+    return svk_cell_ink_ratio(cells, B, cell_px, ratio, otsu, S(stream));
+}
+
 extern "C" int sv_preprocess_cells_u8(sv_ctx *ctx, const uint8_t *cells, long B, uint8_t *out, void *stream)
 {
     REQUIRE(ctx && cells && out, "NULL argument");

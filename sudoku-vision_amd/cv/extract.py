@@ -36,8 +36,13 @@ def extract_cells(grid_image, cell_size: int = 28, margin_ratio: float = 0.1):
 
 
 def is_cell_empty(cell, threshold: float = 0.02) -> bool:
-    """Otsu-binarised ink ratio below `threshold` (reference cv/extract.py:59-79)."""
-    raise NotImplementedError("is_cell_empty lands with scope row N3 (not on pipeline/run.py's path)")
+    """True if the Otsu-binarised ink share of the cell is below `threshold` (reference cv/extract.py:59-79)."""
+    ctx = _rt.default_context()
+    d, _ = _to_dev(cell, ctx)
+    if d.dim() != 2:
+        raise ValueError("is_cell_empty expects a grayscale cell")
+    ratio, _ = ctx.cell_ink_ratio(d[None])
+    return bool(float(ratio[0]) < threshold)
 
 
 def preprocess_cell_for_model(cell):

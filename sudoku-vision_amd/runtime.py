@@ -145,6 +145,15 @@ class Context:
     # ---- K3 -----------------------------------------------------------------------------------
     GLUE_NORMALIZE, GLUE_RUNPY = 0, 1
 
+    def cell_ink_ratio(self, cells):
+        """cells u8 [B,h,w] -> (ratio f32 [B], otsu i32 [B]): is_cell_empty's Otsu ink share, batched."""
+        B = cells.shape[0]
+        ratio = torch.empty((B,), dtype=torch.float32, device=self.device)
+        otsu = torch.empty((B,), dtype=torch.int32, device=self.device)
+        _native.check(_native.lib().sv_cell_ink_ratio_u8(self._h, _ptr(cells), B, int(cells[0].numel()), _ptr(ratio), _ptr(otsu), _stream_ptr()),
+                      "sv_cell_ink_ratio_u8")
+        return ratio, otsu
+
     def preprocess_cells(self, cells):
         """run.py's preprocess_cell on u8 cells [B,28,28] -> u8 {0,255} [B,28,28]."""
         out = torch.empty_like(cells)

@@ -242,3 +242,18 @@ def test_preprocess_cells_and_runpy_glue(ctx, golden_dir):
     el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(exp)[:, None])
     assert np.abs(logits.cpu().numpy() - el.numpy()).max() <= LOGIT_TOL
     assert (digits.cpu().numpy() == ed.numpy()).all()
+
+
+def test_is_cell_empty_batched(ctx):
+    """N3: Otsu + ink ratio per cell, fp64 recurrence in the reference's order -> identical thresholds and ratios."""
+    from sudoku_vision_amd.cv.extract import is_cell_empty
+    rs = np.random.RandomState(23)
+    frames, corners, _ = _frames(1, 540, 960, seed=43)
+    cells = np.concatenate([o.warp_cells(frames[0].cpu().numpy(), corners[0]), rs.randint(0, 256, (20, 28, 28)).astype(np.uint8),
+                            np.full((1, 28, 28), 200, np.uint8)])
+    ratio, otsu = ctx.cell_ink_ratio(torch.from_numpy(cells).cuda())
+    exp = [o.cell_ink_ratio(c) for c in cells]
+    assert (otsu.cpu().numpy() == np.array([e[1] for e in exp])).all()
+    assert np.allclose(ratio.cpu().numpy(), np.array([e[0] for e in exp], np.float32), rtol=0, atol=1e-7)
+    for i in (0, 5, 40, 81, 101):
+        assert is_cell_empty(cells[i]) == o.is_cell_empty(cells[i])

@@ -233,3 +233,25 @@ def test_preprocess_cells_definition():
         assert (got[i] == o.adaptive_threshold(o.clahe(cells[i]), 11, 2, inv=False)).all()
     x = o.cells_to_input(got)
     assert set(np.unique(x)) <= {-1.0, 1.0} and ((x == -1.0) == (got == 255)).all()
+
+
+# ---- N3: is_cell_empty (cv/extract.py:59-79) -------------------------------------------------------------
+def test_otsu_against_exhaustive_search():
+    rs = np.random.RandomState(19)
+    for k in range(6):
+        cell = np.clip(np.where(rs.uniform(size=(28, 28)) < 0.2, rs.normal(60, 12, (28, 28)), rs.normal(190, 15, (28, 28))), 0, 255).astype(np.uint8)
+        ratio, t = o.cell_ink_ratio(cell)
+        best, arg = -1.0, 0                         # between-class variance maximiser, the textbook way in float64
+        flat = cell.ravel().astype(np.float64)
+        for th in range(256):
+            a, b = flat[flat <= th], flat[flat > th]
+            if len(a) == 0 or len(b) == 0:
+                continue
+            s = len(a) * len(b) * (a.mean() - b.mean()) ** 2
+            if s > best * (1 + 1e-12):
+                best, arg = s, th
+        assert abs(t - arg) <= 1
+        assert ratio == (cell <= t).mean()
+        assert o.is_cell_empty(cell) is False       # 20 % ink
+    assert o.cell_ink_ratio(np.full((28, 28), 200, np.uint8)) == (0.0, 0)     # constant cell: threshold 0, no ink
+    assert o.is_cell_empty(np.full((28, 28), 200, np.uint8)) is True

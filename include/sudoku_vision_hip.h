@@ -165,6 +165,10 @@ typedef enum sv_glue {
                                run.py:73-95, then the same invert + normalise -- exactly what run.py feeds the model */
 } sv_glue;
 
+/* cv2.resize(img, (dw, dh)), default INTER_LINEAR, on an 8-bit gray image (cv/extract.py:52 and :93). */
+int sv_resize_linear_u8(sv_ctx *ctx, const uint8_t *src /*dev*/, int sh, int sw, ptrdiff_t pitch,
+                        uint8_t *dst /*dev, dh*dw*/, int dh, int dw, void *stream);
+
 /* is_cell_empty(), cv/extract.py:59-79, batched: per cell the Otsu threshold (cv2.threshold THRESH_OTSU) and
  * ratio = countNonZero(BINARY_INV image) / pixels; the caller compares ratio < threshold (default 0.02).
  * cells: B images of cell_px pixels each.  otsu may be NULL. */

@@ -116,6 +116,23 @@ __global__ __launch_bounds__(256) void k_extract_cells(const u8 *__restrict__ gr
     }
 }
 
+// cv2.resize(img, (dw, dh)) INTER_LINEAR on a gray 8-bit image (cv/extract.py:52,93): one thread per output pixel
+__global__ void k_resize_linear(const u8 *__restrict__ src, int sh, int sw, ptrdiff_t pitch, u8 *__restrict__ dst, int dh, int dw)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    if (sh == dh && sw == dw) { dst[(ptrdiff_t)y * dw + x] = src[(ptrdiff_t)y * pitch + x]; return; }   // same size = copy
+    int xo, a0, a1, yo, b0, b1;
+    sv_resize_axis(sw, dw, x, xo, a0, a1);
+    sv_resize_axis(sh, dh, y, yo, b0, b1);
+    if (xo < 0) { xo = 0; a0 = 2048; a1 = 0; }
+    if (xo >= sw - 1) { xo = sw - 1; a0 = 2048; a1 = 0; }
+    const int x1 = xo + 1 < sw ? xo + 1 : xo;
+    const u8 *r0 = src + (ptrdiff_t)sv_clamp(yo, 0, sh - 1) * pitch, *r1 = src + (ptrdiff_t)sv_clamp(yo + 1, 0, sh - 1) * pitch;
+    const int t0 = r0[xo] * a0 + r0[x1] * a1, t1 = r1[xo] * a0 + r1[x1] * a1;
+    dst[(ptrdiff_t)y * dw + x] = (u8)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2);
+}
+
 // is_cell_empty (cv/extract.py:59-79): Otsu threshold (OpenCV's single-pass fp64 recurrence, executed by one lane
 // in the reference's operation order) of each cell, then the share of pixels <= threshold.  One wave per cell.
 __global__ __launch_bounds__(64) void k_cell_ink_ratio(const u8 *__restrict__ cells, int npx, float *__restrict__ ratio, int *__restrict__ otsu)
@@ -160,6 +177,13 @@ __global__ __launch_bounds__(64) void k_cell_ink_ratio(const u8 *__restrict__ ce
 }
 
 }  // namespace
+
+int svk_resize_linear(const u8 *src, int sh, int sw, ptrdiff_t pitch, u8 *dst, int dh, int dw, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_resize_linear, dim3((dw + 127) / 128, dh), dim3(128), 0, s, src, sh, sw, pitch, dst, dh, dw);
+    SV_LAUNCH_CHECK("k_resize_linear");
+    return SV_OK;
+}
 
 int svk_cell_ink_ratio(const u8 *cells, long B, int npx, float *ratio, int *otsu, hipStream_t s)
 {

@@ -389,6 +389,13 @@ extern "C" int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells, long B
     return cnn_common(ctx, cells, true, glue, B, logits, digits, conf, stream);
 }
 
+extern "C" int sv_resize_linear_u8(sv_ctx *ctx, const uint8_t *src, int sh, int sw, ptrdiff_t pitch, uint8_t *dst, int dh, int dw, void *stream)
+{
+    REQUIRE(ctx && src && dst, "NULL argument");
+    REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0 && dh < 65536 && pitch >= sw, "bad shape");
+    return svk_resize_linear(src, sh, sw, pitch, dst, dh, dw, S(stream));
+}
+
 extern "C" int sv_cell_ink_ratio_u8(sv_ctx *ctx, const uint8_t *cells, long B, int cell_px, float *ratio, int *otsu, void *stream)
 {
     REQUIRE(ctx && cells && ratio, "NULL argument");

@@ -51,5 +51,6 @@ def preprocess_cell_for_model(cell):
     if len(cell.shape) == 3:
         cell = package().cv.preprocess.grayscale(cell)
     if cell.shape != (28, 28):
-        raise NotImplementedError("preprocess_cell_for_model: only 28x28 cells (what extract_cells returns) are supported")
+        ctx = _rt.default_context()
+        cell = ctx.resize_linear(_to_dev(cell, ctx)[0], (28, 28)).cpu().numpy()
     return (cell.astype(np.float32) / 255.0).reshape(1, 28, 28)

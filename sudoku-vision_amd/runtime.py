@@ -145,6 +145,14 @@ class Context:
     # ---- K3 -----------------------------------------------------------------------------------
     GLUE_NORMALIZE, GLUE_RUNPY = 0, 1
 
+    def resize_linear(self, img, dsize):
+        """cv2.resize(img, dsize=(w, h)) INTER_LINEAR on a gray u8 image."""
+        dw, dh = dsize
+        out = torch.empty((dh, dw), dtype=torch.uint8, device=self.device)
+        _native.check(_native.lib().sv_resize_linear_u8(self._h, _ptr(img), img.shape[0], img.shape[1], img.shape[1], _ptr(out), dh, dw, _stream_ptr()),
+                      "sv_resize_linear_u8")
+        return out
+
     def cell_ink_ratio(self, cells):
         """cells u8 [B,h,w] -> (ratio f32 [B], otsu i32 [B]): is_cell_empty's Otsu ink share, batched."""
         B = cells.shape[0]

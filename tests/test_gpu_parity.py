@@ -271,3 +271,35 @@ def test_resize_and_preprocess_cell_for_model(ctx):
         assert (x[0] == o.resize_linear(img, (28, 28)).astype(np.float32) / 255.0).all()
     up = ctx.resize_linear(torch.from_numpy(img).cuda(), (100, 90)).cpu().numpy()
     assert (up == o.resize_linear(img, (100, 90))).all()
+
+
+def test_error_behaviour_on_gpu(ctx):
+    """Status codes -> exceptions: no weights, unsupported parameters, bad shapes; and the context survives them."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd._native import NativeError
+    fresh = sva.Context()
+    with pytest.raises(NativeError, match="SV_ERR_NO_WEIGHTS"):
+        fresh.cnn_forward(torch.zeros((2, 1, 28, 28), device="cuda"))
+    g = torch.zeros((1, 32, 32), dtype=torch.uint8, device="cuda")
+    with pytest.raises(NativeError, match="SV_ERR_UNSUPPORTED"):
+        fresh.blur(g, 9)
+    with pytest.raises(NativeError, match="SV_ERR_BAD_ARG"):
+        fresh.blur(g, 4)
+    with pytest.raises(NativeError, match="SV_ERR_BAD_ARG"):
+        fresh.adaptive_threshold(g, 10, 2)
+    with pytest.raises(NativeError, match="SV_ERR_UNSUPPORTED"):
+        fresh.adaptive_threshold(g, 33, 2)
+    ctx.load_state_dict(cnn_oracle.random_state_dict(1))
+    with pytest.raises(NativeError, match="SV_ERR_BAD_ARG"):
+        ctx.cnn_forward(torch.zeros((1, 28, 28), dtype=torch.uint8, device="cuda"), glue=7)
+    assert (fresh.blur(g, 5) == 0).all()                       # still usable
+    fresh.close()
+
+
+def test_tiny_and_odd_images(ctx):
+    """Smallest shapes the reference's functions accept: every border path at once."""
+    rs = np.random.RandomState(31)
+    for H, W in ((1, 1), (2, 3), (5, 5), (11, 7), (16, 16), (17, 20), (33, 260)):
+        img = rs.randint(0, 256, (1, H, W, 3)).astype(np.uint8)
+        got = ctx.preprocess(torch.from_numpy(img).cuda()).cpu().numpy()
+        assert (got[0] == o.preprocess_for_grid_detection(img[0])).all(), (H, W)

@@ -141,7 +141,7 @@ def main():
         err = np.abs(res_e2e["corners"].astype(np.float32)[:, :, None, :] - corners[:, None, :, :]).sum(-1).min(-1).max()
         e2e = {"value": n * args.e2e_passes * world / dt, "unit": "frames/s", "host_threads_per_gpu": host_threads,
                "grids_found": int(res_e2e["found"].sum()), "of": n, "max_corner_error_px": float(err),
-               "note": "K1 -> pinned D2H (2.07 MB/frame over PCIe) -> C++ contour corner search on host threads -> K2 -> K3, 32-frame chunks double-buffered"}
+               "note": "K1 -> despeckle (exact speck filter) -> pinned D2H (2.07 MB/frame over PCIe) -> C++ contour corner search on host threads -> K2 -> K3, 32-frame chunks double-buffered"}
 
     if rank == 0:
         total_frames = n * args.steps * world

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2]: one camera feed at 30 fps, per-frame latency of the hot path on one MI355X.
 
-Per frame:  pinned host frame --H2D--> K1 --D2H binary--> host contour corner search --> Minv --H2D--> K2 -> K3
+Per frame:  pinned host frame --H2D--> K1 -> despeckle --D2H binary--> host contour corner search --> Minv --H2D--> K2 -> K3
             --D2H--> 81 digits.   The two device segments (K1; K2->K3) are hipGraph-captured once and replayed.
 Reports p50/p90/p99 of (a) the whole frame -> digits latency as a host clock around it, (b) its device segments.
 Prints one JSON line.  Not the headline metric (that is bench.py)."""
@@ -55,7 +55,7 @@ def main():
         stream.synchronize()
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, stream=stream):
-            binary_d.copy_(ctx.preprocess(frame_d))
+            ctx.despeckle(ctx.preprocess(frame_d), out=binary_d)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=stream):
             ctx.frames_to_digits(frame_d, minv_d, out=out, glue=args.glue)

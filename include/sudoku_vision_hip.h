@@ -96,6 +96,13 @@ int sv_adaptive_threshold_u8(sv_ctx *ctx, const uint8_t *src /*dev, n*H*W*/, int
 int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch,
                      ptrdiff_t img_stride, uint8_t *binary /*dev, n*H*W*/, void *stream);
 
+/* Accelerator for the host corner search, not a reference stage: erases every connected component of a {0,255}
+ * image that lies strictly inside a 64x64 tile (two offset tile grids).  Such components can neither be nor
+ * influence the result of find_grid_contour (argument in csrc/k4_despeckle.hip), so
+ * sv_find_grid_corners_u8(despeckled) == sv_find_grid_corners_u8(binary).  out may equal binary. */
+int sv_despeckle_u8(sv_ctx *ctx, const uint8_t *binary /*dev, n*H*W*/, int n, int H, int W,
+                    uint8_t *out /*dev, n*H*W*/, void *stream);
+
 /* ---- host corner search (cv/grid.py:16-71; stays on the CPU, no context, no GPU) ----------------- */
 
 /* find_grid_contour(binary, min_area_ratio), cv/grid.py:37-71, with approximate_polygon's

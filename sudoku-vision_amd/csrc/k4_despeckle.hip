@@ -1,0 +1,117 @@
+// Despeckle -- an exact accelerator for the HOST corner search (cv/grid.py:37-71), not a reference stage.
+//
+// The thresholded frame holds ~24,000 connected components, almost all of them noise specks a few pixels
+// across; following their borders is what the host search spends its time on.  A component that lies strictly
+// inside a 64x64 tile (touches none of the tile's outermost pixels) has a bounding box under 62x62 px, so it can
+// never reach find_grid_contour's area floor (10 % of the frame), and erasing it cannot change how any other
+// border is followed (Suzuki-Abe only ever looks at 8-neighbours of the component being traced) nor whether a
+// later component counts as external (a traced speck always leaves a "right-exit" mark behind, i.e. the same
+// outside-state the scan had before it).  So find_grid_contour(despeckle(b)) == find_grid_contour(b); the tests
+// check exactly that.  preprocess_for_grid_detection's own output is never altered -- this runs on a copy.
+//
+// One wave per tile, one lane per tile row, the row held as a 64-bit mask.  Seeds = foreground pixels on the
+// tile's outer ring; flood fill by Jacobi iteration: within a row a seed spreads along its run with one
+// carry-propagating add per direction, between rows through DPP lane shifts.  Stops when a wave-wide ballot
+// sees no change (or after MAX_IT iterations, in which case the tile is left untouched).  Two passes with the
+// tile grid offset by (32,32) catch specks that straddle a tile edge of the first pass.
+#include "sv_device.h"
+#include "sv_internal.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+__device__ __forceinline__ u64 lane_shift_up(u64 v)     // lane i receives lane i-1's value (0 into lane 0)
+{
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x138, 0xf, 0xf, true);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x138, 0xf, 0xf, true);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 lane_shift_down(u64 v)   // lane i receives lane i+1's value (0 into lane 63)
+{
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x130, 0xf, 0xf, true);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x130, 0xf, 0xf, true);
+    return ((u64)hi << 32) | lo;
+}
+// all bits of the runs of `f` that contain a bit of `g` (g subset of f)
+__device__ __forceinline__ u64 fill_runs(u64 f, u64 g)
+{
+    u64 up = ((f + g) ^ f) & f;                       // from each seed towards the MSB end of its run
+    const u64 fr = __brevll(f), gr = __brevll(g | up);
+    const u64 dn = ((fr + gr) ^ fr) & fr;             // and, bit-reversed, towards the LSB end
+    return g | up | __brevll(dn);
+}
+
+constexpr int T = 64, MAX_IT = 96;
+
+__global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u8 *__restrict__ dst, int H, int W, int ox, int oy,
+                                                   int tiles_x, int tiles_y, long ntiles)
+{
+    const int lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+    const long frame = tile / ((long)tiles_x * tiles_y);
+    const int x0 = tx * T - ox, y0 = ty * T - oy, y = y0 + lane;
+    const u8 *row = src + (frame * H + (y < 0 ? 0 : (y >= H ? H - 1 : y))) * (long)W;
+    const bool row_ok = y >= 0 && y < H;
+    const bool fast = row_ok && x0 >= 0 && x0 + T <= W && ((W | x0) & 3) == 0;
+
+    u64 f = 0;
+    if (fast) {
+        const u32 *p = (const u32 *)(row + x0);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 d = p[k] & 0x01010101u;          // pixels are 0 or 255
+            f |= (u64)(((d * 0x10204080u) >> 28) & 0xF) << (4 * k);   // bytes 0..3 -> bits 0..3
+        }
+    } else if (row_ok) {
+        for (int k = 0; k < T; k++) {
+            const int x = x0 + k;
+            if (x >= 0 && x < W && row[x]) f |= 1ull << k;
+        }
+    }
+    const u64 ring = (lane == 0 || lane == T - 1) ? ~0ull : 0x8000000000000001ull;
+    u64 g = fill_runs(f, f & ring);
+    bool converged = false;
+    for (int it = 0; it < MAX_IT; it++) {
+        const u64 nb = g | lane_shift_up(g) | lane_shift_down(g);
+        const u64 seeds = f & (nb | (nb << 1) | (nb >> 1));          // 8-connectivity
+        const u64 g2 = fill_runs(f, g | seeds);
+        const bool changed = g2 != g;
+        g = g2;
+        if (!__any(changed)) { converged = true; break; }
+    }
+    const u64 keep = converged ? g : f;
+    if (src == dst && keep == f) return;                              // nothing to erase in this row
+    u8 *orow = dst + (frame * H + y) * (long)W;
+    if (fast) {
+        u32 *q = (u32 *)(orow + x0);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 b = (u32)(keep >> (4 * k)) & 0xF;
+            q[k] = (((b * 0x00204081u) & 0x01010101u) * 255u);       // bits 0..3 -> bytes 0..3 of 0/255
+        }
+    } else if (row_ok) {
+        for (int k = 0; k < T; k++) {
+            const int x = x0 + k;
+            if (x >= 0 && x < W) orow[x] = (keep >> k) & 1 ? 255 : 0;
+        }
+    }
+}
+
+}  // namespace
+
+// two passes (tile grids offset by half a tile); dst may equal src
+int svk_despeckle(const u8 *src, int n, int H, int W, u8 *dst, hipStream_t s)
+{
+    for (int pass = 0; pass < 2; pass++) {
+        const int o = pass ? T / 2 : 0;
+        const int tiles_x = (W + o + T - 1) / T, tiles_y = (H + o + T - 1) / T;
+        const long ntiles = (long)n * tiles_x * tiles_y;
+        hipLaunchKernelGGL(k_despeckle, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, pass ? dst : src, dst, H, W, o, o, tiles_x, tiles_y, ntiles);
+        SV_LAUNCH_CHECK("k_despeckle");
+    }
+    return SV_OK;
+}

@@ -2,7 +2,7 @@
 of the hot section of pipeline/run.py:244-312 (call order, glue, output conventions), batched and
 software-pipelined for a resident pool of frames:
 
-    GPU  K1 (binary)  --D2H, pinned-->  CPU contour corner search (threads)  --Minv, H2D-->  GPU  K2 -> K3
+    GPU  K1 (binary) -> despeckle  --D2H, pinned-->  CPU contour corner search (threads)  --Minv, H2D-->  GPU  K2 -> K3
 
 Chunks of frames are double-buffered: while the host searches chunk i, the GPU thresholds chunk i+1 and
 classifies chunk i-1.  `glue` selects what sits between extract_cells and the model (see include/sudoku_vision_hip.h sv_glue).
@@ -19,10 +19,11 @@ from .runtime import Context
 
 
 class FramePipeline:
-    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1, glue=0):
+    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1, glue=0, despeckle=True):
         self.ctx, self.H, self.W, self.chunk = ctx, H, W, chunk
         self.host_threads = host_threads or max(1, (os.cpu_count() or 2) - 1)
         self.min_area_ratio = min_area_ratio
+        self.despeckle = despeckle
         self.glue = glue            # Context.GLUE_NORMALIZE, or GLUE_RUNPY for run.py's preprocess_cell (CLAHE + threshold)
         dev = ctx.device
         self.s_pre = torch.cuda.Stream(dev)       # K1 + D2H
@@ -81,6 +82,8 @@ class FramePipeline:
                 free_ev[slot].synchronize()
             with torch.cuda.stream(self.s_pre):
                 b = self.ctx.preprocess(frames[s:s + m])
+                # exact accelerator for the host search: erase the specks that cannot matter (csrc/k4_despeckle.hip)
+                b = self.ctx.despeckle(b, out=self.dev_bin[slot][:m]) if self.despeckle else b
                 self.pinned[slot][:m].copy_(b, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.s_pre)

@@ -105,6 +105,14 @@ class Context:
         _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
         return out
 
+    def despeckle(self, binary, out=None):
+        """binary u8 [n,H,W] in {0,255} -> the same with every component that fits strictly inside a 64x64 tile erased
+        (find_grid_contour-equivalent; used only to make the host corner search cheaper)."""
+        n, H, W = binary.shape
+        out = torch.empty_like(binary) if out is None else out
+        _native.check(_native.lib().sv_despeckle_u8(self._h, _ptr(binary), n, H, W, _ptr(out), _stream_ptr()), "sv_despeckle_u8")
+        return out
+
     # ---- K2 -----------------------------------------------------------------------------------
     @staticmethod
     def corners_to_minv(corners, output_size=450, inset_ratio=0.0):

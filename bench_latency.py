@@ -38,7 +38,8 @@ def main():
     ctx.reserve(81)
 
     frame_d = torch.empty((1, H, W, 3), dtype=torch.uint8, device="cuda")
-    binary_h = torch.empty((1, H, W), dtype=torch.uint8).pin_memory()
+    binary_h = torch.empty((1, H, W // 32), dtype=torch.int32).pin_memory()        # 1 bit per pixel over PCIe
+    bits_d = torch.empty((1, H, W // 32), dtype=torch.int32, device="cuda")
     minv_h = torch.empty((1, 9), dtype=torch.float64).pin_memory()
     minv_d = torch.empty((1, 9), dtype=torch.float64, device="cuda")
     out = {"logits": torch.empty((1, 81, 10), device="cuda"), "digits": torch.empty((1, 81), dtype=torch.uint8, device="cuda"),
@@ -55,7 +56,7 @@ def main():
         stream.synchronize()
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, stream=stream):
-            ctx.despeckle(ctx.preprocess(frame_d), out=binary_d)
+            ctx.despeckle(ctx.preprocess(frame_d), out=binary_d, packed=bits_d)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=stream):
             ctx.frames_to_digits(frame_d, minv_d, out=out, glue=args.glue)
@@ -73,10 +74,11 @@ def main():
         with torch.cuda.stream(stream):
             frame_d[0].copy_(src, non_blocking=True)
             g1.replay()
-            binary_h.copy_(binary_d, non_blocking=True)
+            binary_h.copy_(bits_d, non_blocking=True)
             stream.synchronize()
             t1 = time.perf_counter()
-            c = sva.host.find_grid_corners(binary_h[0].numpy())
+            cc, ff = sva.host.find_grid_corners_bits_batch(binary_h.numpy(), H, W, threads=1)
+            c = cc[0] if ff[0] else None
             t2 = time.perf_counter()
             if c is not None:
                 found += 1

@@ -99,9 +99,12 @@ int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int 
 /* Accelerator for the host corner search, not a reference stage: erases every connected component of a {0,255}
  * image that lies strictly inside a 64x64 tile (two offset tile grids).  Such components can neither be nor
  * influence the result of find_grid_contour (argument in csrc/k4_despeckle.hip), so
- * sv_find_grid_corners_u8(despeckled) == sv_find_grid_corners_u8(binary).  out may equal binary. */
+ * sv_find_grid_corners_u8(despeckled) == sv_find_grid_corners_u8(binary).  out may equal binary.
+ * packed (optional, needs W % 32 == 0): the result as 1 bit per pixel (LSB = leftmost, W/32 words per row) for a
+ * cheap D2H copy -- when given, `out` is scratch (first pass only) and `packed` holds the result; feed it to
+ * sv_find_grid_corners_bits_batch. */
 int sv_despeckle_u8(sv_ctx *ctx, const uint8_t *binary /*dev, n*H*W*/, int n, int H, int W,
-                    uint8_t *out /*dev, n*H*W*/, void *stream);
+                    uint8_t *out /*dev, n*H*W*/, uint32_t *packed /*dev, n*H*W/32, or NULL*/, void *stream);
 
 /* ---- host corner search (cv/grid.py:16-71; stays on the CPU, no context, no GPU) ----------------- */
 
@@ -117,6 +120,11 @@ int sv_find_grid_corners_u8(const uint8_t *binary /*host*/, int H, int W, ptrdif
 int sv_find_grid_corners_batch_u8(const uint8_t *binary /*host*/, int n, int H, int W, ptrdiff_t pitch,
                                   ptrdiff_t img_stride, double min_area_ratio, double epsilon_ratio,
                                   int *corners /*host, n*8*/, uint8_t *found /*host, n*/, int threads);
+
+/* sv_find_grid_corners_batch_u8 on bit-packed images (layout of sv_despeckle_u8's `packed`). */
+int sv_find_grid_corners_bits_batch(const uint32_t *bits /*host, n*H*W/32*/, int n, int H, int W,
+                                    double min_area_ratio, double epsilon_ratio,
+                                    int *corners /*host, n*8*/, uint8_t *found /*host, n*/, int threads);
 
 /* find_contours(), cv/grid.py:16-21.  Contours in cv2's order, concatenated: points = (x,y) pairs,
  * sizes[i] = vertices of contour i.  If a buffer is too small (or NULL) returns SV_ERR_BUFFER with

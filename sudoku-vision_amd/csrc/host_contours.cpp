@@ -12,6 +12,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -38,6 +42,27 @@ class BorderScanner {
             const u8 *s = bin + (ptrdiff_t)y * pitch;
             int8_t *d = img_.data() + (size_t)(y + 1) * step_ + 1;
             for (int x = 0; x < W; x++) d[x] = s[x] != 0;
+        }
+        for (int k = 0; k < 8; k++) delta_[k] = delta_[k + 8] = kDy[k] * step_ + kDx[k];
+    }
+
+    // from a bit-packed image: 1 bit per pixel, LSB = leftmost, W/32 words per row (sv_despeckle_u8's packed output)
+    BorderScanner(const uint32_t *bits, int H, int W) : h_(H), w_(W), step_(W + 2), img_((size_t)(W + 2) * (H + 2), 0)
+    {
+        const int wpr = W >> 5;
+        for (int y = 0; y < H; y++) {
+            const uint32_t *s = bits + (size_t)y * wpr;
+            int8_t *d = img_.data() + (size_t)(y + 1) * step_ + 1;
+            for (int k = 0; k < wpr; k++) {
+                uint32_t v = s[k];
+                if (!v) continue;                              // rows are mostly empty after despeckling
+                for (int b = 0; b < 4; b++, v >>= 8) {
+                    // 8 bits -> 8 bytes of 0/1
+                    uint64_t x = (uint64_t)(v & 0xFF) * 0x0101010101010101ull & 0x8040201008040201ull;
+                    x = ((x + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+                    memcpy(d + 32 * k + 8 * b, &x, 8);
+                }
+            }
         }
         for (int k = 0; k < 8; k++) delta_[k] = delta_[k + 8] = kDy[k] * step_ + kDx[k];
     }
@@ -268,10 +293,17 @@ std::vector<Pt> approx_poly(const Pt *src, int count, double eps, bool closed_in
     return dst;
 }
 
+bool grid_corners_from(BorderScanner &sc, int H, int W, double min_area_ratio, double eps_ratio, int *out8);
+
 // find_grid_contour, cv/grid.py:37-71
 bool grid_corners(const u8 *bin, int H, int W, ptrdiff_t pitch, double min_area_ratio, double eps_ratio, int *out8)
 {
     BorderScanner sc(bin, H, W, pitch);
+    return grid_corners_from(sc, H, W, min_area_ratio, eps_ratio, out8);
+}
+
+bool grid_corners_from(BorderScanner &sc, int H, int W, double min_area_ratio, double eps_ratio, int *out8)
+{
     sc.run();
     const double min_area = min_area_ratio * ((double)H * (double)W);
     struct Cand { double area; size_t idx; };
@@ -297,6 +329,77 @@ bool grid_corners(const u8 *bin, int H, int W, ptrdiff_t pitch, double min_area_
     return false;
 }
 
+// A small persistent worker pool: batch calls arrive every millisecond or so in the streaming pipeline, and spawning
+// 16 std::threads per call cost about as much as the search itself.  parallel_for(n, threads, fn) runs fn(i) for
+// i in [0,n) on up to `threads` workers (dynamic index hand-out) and returns when all are done.
+class WorkerPool {
+  public:
+    static WorkerPool &instance() { static WorkerPool p; return p; }
+
+    void parallel_for(int n, int threads, const std::function<void(int)> &fn)
+    {
+        if (threads <= 1 || n <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+        std::unique_lock<std::mutex> call_lock(call_mu_);          // one batch at a time
+        ensure(threads - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_ = n; next_.store(0); active_ = std::min(threads - 1, (int)workers_.size()); pending_ = active_; gen_++;
+        }
+        cv_.notify_all();
+        drain();                                                    // the calling thread works too
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    WorkerPool() = default;
+    ~WorkerPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void ensure(int k)
+    {
+        while ((int)workers_.size() < k) {
+            const int id = (int)workers_.size();
+            workers_.emplace_back([this, id] { loop(id); });
+        }
+    }
+    void drain()
+    {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+        }
+    }
+    void loop(int id)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            if (id >= active_) continue;
+            lk.unlock();
+            drain();
+            lk.lock();
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::mutex call_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, active_ = 0, pending_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+
 }  // namespace
 
 // ---- C ABI -------------------------------------------------------------------------------------------
@@ -313,17 +416,22 @@ extern "C" int sv_find_grid_corners_batch_u8(const uint8_t *binary, int n, int H
     if (!binary || !corners || !found || n <= 0 || H <= 0 || W <= 0 || pitch < W) return sv_fail(SV_ERR_BAD_ARG, "sv_find_grid_corners_batch_u8: bad argument");
     if (threads < 1) threads = 1;
     if (threads > n) threads = n;
-    auto work = [&](int t) {
-        for (int i = t; i < n; i += threads)
-            found[i] = grid_corners(binary + (ptrdiff_t)i * img_stride, H, W, pitch, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
-    };
-    if (threads == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
-    }
+    WorkerPool::instance().parallel_for(n, threads, [&](int i) {
+        found[i] = grid_corners(binary + (ptrdiff_t)i * img_stride, H, W, pitch, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
+    });
+    return SV_OK;
+}
+
+extern "C" int sv_find_grid_corners_bits_batch(const uint32_t *bits, int n, int H, int W, double min_area_ratio, double epsilon_ratio, int *corners,
+                                               uint8_t *found, int threads)
+{
+    if (!bits || !corners || !found || n <= 0 || H <= 0 || W <= 0 || (W & 31)) return sv_fail(SV_ERR_BAD_ARG, "sv_find_grid_corners_bits_batch: bad argument");
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    WorkerPool::instance().parallel_for(n, threads, [&](int i) {
+        BorderScanner sc(bits + (size_t)i * H * (W >> 5), H, W);
+        found[i] = grid_corners_from(sc, H, W, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
+    });
     return SV_OK;
 }
 

@@ -45,8 +45,8 @@ __device__ __forceinline__ u64 fill_runs(u64 f, u64 g)
 
 constexpr int T = 64, MAX_IT = 96;
 
-__global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u8 *__restrict__ dst, int H, int W, int ox, int oy,
-                                                   int tiles_x, int tiles_y, long ntiles)
+__global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u8 *__restrict__ dst, u32 *__restrict__ packed, int H, int W,
+                                                   int ox, int oy, int tiles_x, int tiles_y, long ntiles)
 {
     const int lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -84,6 +84,14 @@ __global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u
         if (!__any(changed)) { converged = true; break; }
     }
     const u64 keep = converged ? g : f;
+    if (packed) {                     // bit-packed result (1 bit per pixel, LSB first, W/32 words per row) for the D2H copy
+        if (row_ok) {
+            u32 *prow = packed + (frame * H + y) * (long)(W >> 5);
+            if (x0 >= 0 && x0 < W) prow[x0 >> 5] = (u32)keep;
+            if (x0 + 32 >= 0 && x0 + 32 < W) prow[(x0 + 32) >> 5] = (u32)(keep >> 32);
+        }
+        return;
+    }
     if (src == dst && keep == f) return;                              // nothing to erase in this row
     u8 *orow = dst + (frame * H + y) * (long)W;
     if (fast) {
@@ -103,14 +111,16 @@ __global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u
 
 }  // namespace
 
-// two passes (tile grids offset by half a tile); dst may equal src
-int svk_despeckle(const u8 *src, int n, int H, int W, u8 *dst, hipStream_t s)
+// two passes (tile grids offset by half a tile); dst may equal src.  With `packed` (needs W % 32 == 0) the second pass
+// writes 1 bit per pixel there instead of bytes into dst (dst then holds the first pass only and serves as scratch).
+int svk_despeckle(const u8 *src, int n, int H, int W, u8 *dst, u32 *packed, hipStream_t s)
 {
     for (int pass = 0; pass < 2; pass++) {
         const int o = pass ? T / 2 : 0;
         const int tiles_x = (W + o + T - 1) / T, tiles_y = (H + o + T - 1) / T;
         const long ntiles = (long)n * tiles_x * tiles_y;
-        hipLaunchKernelGGL(k_despeckle, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, pass ? dst : src, dst, H, W, o, o, tiles_x, tiles_y, ntiles);
+        hipLaunchKernelGGL(k_despeckle, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, pass ? dst : src, dst, pass ? packed : (u32 *)nullptr, H, W, o, o,
+                           tiles_x, tiles_y, ntiles);
         SV_LAUNCH_CHECK("k_despeckle");
     }
     return SV_OK;

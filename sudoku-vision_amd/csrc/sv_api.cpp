@@ -343,11 +343,12 @@ extern "C" int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, i
     return svk_preprocess(ctx, bgr, n, H, W, pitch, img_stride, binary, S(stream));
 }
 
-extern "C" int sv_despeckle_u8(sv_ctx *ctx, const uint8_t *binary, int n, int H, int W, uint8_t *out, void *stream)
+extern "C" int sv_despeckle_u8(sv_ctx *ctx, const uint8_t *binary, int n, int H, int W, uint8_t *out, uint32_t *packed, void *stream)
 {
     REQUIRE(ctx && binary && out, "NULL argument");
     REQUIRE(n > 0 && H > 0 && W > 0, "bad shape");
-    return svk_despeckle(binary, n, H, W, out, S(stream));
+    REQUIRE(!packed || W % 32 == 0, "packed output needs W % 32 == 0");
+    return svk_despeckle(binary, n, H, W, out, packed, S(stream));
 }
 
 extern "C" int sv_warp_perspective_u8(sv_ctx *ctx, const uint8_t *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size, uint8_t *dst, void *stream)

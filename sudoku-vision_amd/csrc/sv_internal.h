@@ -79,7 +79,7 @@ int svk_warp_cells(sv_ctx *ctx, const u8 *frames, int n, int H, int W, ptrdiff_t
 int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, float *logits, u8 *digits, float *conf,
                     hipStream_t s);
 
-int svk_despeckle(const u8 *src, int n, int H, int W, u8 *dst, hipStream_t s);
+int svk_despeckle(const u8 *src, int n, int H, int W, u8 *dst, unsigned *packed, hipStream_t s);
 int svk_resize_linear(const u8 *src, int sh, int sw, ptrdiff_t pitch, u8 *dst, int dh, int dw, hipStream_t s);
 int svk_cell_ink_ratio(const u8 *cells, long B, int npx, float *ratio, int *otsu, hipStream_t s);
 int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s);

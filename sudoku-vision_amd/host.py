@@ -88,3 +88,16 @@ def find_grid_corners_batch(binaries, min_area_ratio=0.1, epsilon_ratio=0.02, th
                                                               float(epsilon_ratio), corners.ctypes.data_as(C.c_void_p),
                                                               found.ctypes.data_as(C.c_void_p), int(threads)), "sv_find_grid_corners_batch_u8")
     return corners, found.astype(bool)
+
+
+def find_grid_corners_bits_batch(bits, H, W, min_area_ratio=0.1, epsilon_ratio=0.02, threads=None):
+    """bits int32/uint32 [n,H,W//32] (host; 1 bit per pixel, LSB = leftmost) -> (corners int32 [n,4,2], found bool [n])."""
+    b = np.ascontiguousarray(bits)
+    n = b.shape[0]
+    corners = np.zeros((n, 4, 2), np.int32)
+    found = np.zeros(n, np.uint8)
+    threads = threads or min(n, os.cpu_count() or 1)
+    _native.check(_native.lib().sv_find_grid_corners_bits_batch(b.ctypes.data_as(C.c_void_p), n, int(H), int(W), float(min_area_ratio), float(epsilon_ratio),
+                                                                corners.ctypes.data_as(C.c_void_p), found.ctypes.data_as(C.c_void_p), int(threads)),
+                  "sv_find_grid_corners_bits_batch")
+    return corners, found.astype(bool)

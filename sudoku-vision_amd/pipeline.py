@@ -28,7 +28,13 @@ class FramePipeline:
         dev = ctx.device
         self.s_pre = torch.cuda.Stream(dev)       # K1 + D2H
         self.s_cls = torch.cuda.Stream(dev)       # H2D + K2 + K3
-        self.pinned = [torch.empty((chunk, H, W), dtype=torch.uint8).pin_memory() for _ in range(3)]
+        # D2H payload: with despeckle on and W % 32 == 0 the binary crosses PCIe as 1 bit per pixel (W/32 words per row)
+        self.packed = despeckle and W % 32 == 0
+        if self.packed:
+            self.pinned = [torch.empty((chunk, H, W // 32), dtype=torch.int32).pin_memory() for _ in range(3)]
+            self.dev_bits = [torch.empty((chunk, H, W // 32), dtype=torch.int32, device=dev) for _ in range(3)]
+        else:
+            self.pinned = [torch.empty((chunk, H, W), dtype=torch.uint8).pin_memory() for _ in range(3)]
         self.dev_bin = [torch.empty((chunk, H, W), dtype=torch.uint8, device=dev) for _ in range(3)]
         self.minv_pin = [torch.empty((chunk, 9), dtype=torch.float64).pin_memory() for _ in range(3)]
         self.minv_dev = [torch.empty((chunk, 9), dtype=torch.float64, device=dev) for _ in range(3)]
@@ -37,16 +43,22 @@ class FramePipeline:
 
     def _search(self, slot, m, ev):
         ev.synchronize()
-        corners, found = host.find_grid_corners_batch(self.pinned[slot][:m].numpy(), self.min_area_ratio, 0.02, self.host_threads)
+        if self.packed:
+            corners, found = host.find_grid_corners_bits_batch(self.pinned[slot][:m].numpy(), self.H, self.W, self.min_area_ratio, 0.02, self.host_threads)
+        else:
+            corners, found = host.find_grid_corners_batch(self.pinned[slot][:m].numpy(), self.min_area_ratio, 0.02, self.host_threads)
         safe = corners.astype(np.float32)
         safe[~found] = np.array([[0, 0], [449, 0], [449, 449], [0, 449]], np.float32)      # any valid quad; result is masked
         self.minv_pin[slot][:m] = torch.from_numpy(Context.corners_to_minv(safe).reshape(m, 9))
         return corners, found
 
-    def run(self, frames, out=None):
+    def run(self, frames, out=None, repeat=1):
         """frames u8 [n,H,W,3] on the context's device -> dict(digits u8[n,81], logits f32[n,81,10], conf f32[n,81],
-        corners int32[n,4,2] (host), found bool[n] (host))."""
+        corners int32[n,4,2] (host), found bool[n] (host)).  repeat > 1 streams the pool that many times through the
+        pipeline without draining it in between (steady-state throughput measurement); needs chunk | n."""
         n = frames.shape[0]
+        if repeat > 1 and n % self.chunk:
+            raise ValueError("repeat needs the chunk size to divide the number of frames")
         dev = self.ctx.device
         if out is None:
             out = {"logits": torch.empty((n, 81, 10), dtype=torch.float32, device=dev),
@@ -57,7 +69,7 @@ class FramePipeline:
         cur = torch.cuda.current_stream(dev)
         self.s_pre.wait_stream(cur)
         self.s_cls.wait_stream(cur)
-        starts = list(range(0, n, self.chunk))
+        starts = [s0 for _ in range(repeat) for s0 in range(0, n, self.chunk)]
         pending = []                                  # (future, slot, start, m)
         free_ev = [None, None, None]                  # classification done with slot's minv buffer
 
@@ -83,7 +95,10 @@ class FramePipeline:
             with torch.cuda.stream(self.s_pre):
                 b = self.ctx.preprocess(frames[s:s + m])
                 # exact accelerator for the host search: erase the specks that cannot matter (csrc/k4_despeckle.hip)
-                b = self.ctx.despeckle(b, out=self.dev_bin[slot][:m]) if self.despeckle else b
+                if self.packed:
+                    b = self.ctx.despeckle(b, out=self.dev_bin[slot][:m], packed=self.dev_bits[slot][:m])
+                elif self.despeckle:
+                    b = self.ctx.despeckle(b, out=self.dev_bin[slot][:m])
                 self.pinned[slot][:m].copy_(b, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.s_pre)

@@ -105,13 +105,15 @@ class Context:
         _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
         return out
 
-    def despeckle(self, binary, out=None):
+    def despeckle(self, binary, out=None, packed=None):
         """binary u8 [n,H,W] in {0,255} -> the same with every component that fits strictly inside a 64x64 tile erased
-        (find_grid_contour-equivalent; used only to make the host corner search cheaper)."""
+        (find_grid_contour-equivalent; used only to make the host corner search cheaper).  packed: optional int32 [n,H,W//32]
+        tensor receiving the result as 1 bit per pixel (then `out` is scratch)."""
         n, H, W = binary.shape
         out = torch.empty_like(binary) if out is None else out
-        _native.check(_native.lib().sv_despeckle_u8(self._h, _ptr(binary), n, H, W, _ptr(out), _stream_ptr()), "sv_despeckle_u8")
-        return out
+        _native.check(_native.lib().sv_despeckle_u8(self._h, _ptr(binary), n, H, W, _ptr(out), _ptr(packed) if packed is not None else None,
+                                                    _stream_ptr()), "sv_despeckle_u8")
+        return out if packed is None else packed
 
     # ---- K2 -----------------------------------------------------------------------------------
     @staticmethod

@@ -319,6 +319,15 @@ def test_despeckle_preserves_grid_search(ctx):
     for i in range(6):
         a, c = sva.host.find_grid_corners(b[i]), sva.host.find_grid_corners(f[i])
         assert (a is None) == (c is None) and (a is None or (a == c).all())
+    # bit-packed output (what crosses PCIe in the pipeline) = the byte output, and the host search on it agrees
+    bits = torch.empty((6, 1080, 1920 // 32), dtype=torch.int32, device="cuda")
+    ctx.despeckle(binary, out=torch.empty_like(binary), packed=bits)
+    unpacked = np.unpackbits(bits.cpu().numpy().view(np.uint8).reshape(6, 1080, -1), axis=2, bitorder="little") * 255
+    assert (unpacked == f).all()
+    cb, fb = sva.host.find_grid_corners_bits_batch(bits.cpu().numpy(), 1080, 1920, threads=3)
+    for i in range(6):
+        a = sva.host.find_grid_corners(b[i])
+        assert fb[i] == (a is not None) and (a is None or (cb[i] == a).all())
     lab, n = ndimage.label(b[0] > 0, structure=np.ones((3, 3)))
     kept = np.unique(lab[f[0] > 0])
     gone = np.setdiff1d(np.unique(lab[(b[0] > 0) & (f[0] == 0)]), [0])

@@ -139,6 +139,13 @@ int sv_arc_length_i32(const int *xy /*host*/, int n, int closed, double *length)
 int sv_approx_poly_dp_i32(const int *xy /*host*/, int n, double epsilon, int closed,
                           int *out /*host, n*2*/, int *n_out);
 
+/* ---- solver (host; scope row N4) -------------------------------------------------------------------- */
+
+/* solve_sudoku(), solver/src/sudoku.c:72-81, as an in-process call instead of pipeline/run.py:163-202's
+ * subprocess + /tmp files.  grid/solution: 81 digits row-major, 0 = empty.  *result: 1 solved, 0 no solution,
+ * -1 invalid input (solver/include/sudoku.h:13-16); solution = grid unless solved. */
+int sv_solve_sudoku(const uint8_t *grid /*host, 81*/, uint8_t *solution /*host, 81*/, int *result);
+
 /* ---- K2: perspective warp + cell extraction (cv/grid.py, cv/extract.py) ------------------------- */
 
 /* Host, fp64.  order_points + inset + cv2.getPerspectiveTransform to (0,0)..(S-1,S-1) + the inverse

@@ -25,6 +25,7 @@ SIGNATURES = {
     "sv_blur_u8": [_p, _p, _i, _i, _i, _i, _p, _p],
     "sv_adaptive_threshold_u8": [_p, _p, _i, _i, _i, _i, _d, _i, _p, _p],
     "sv_preprocess_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
+    "sv_solve_sudoku": [_p, _p, _p],
     "sv_despeckle_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
     "sv_find_grid_corners_bits_batch": [_p, _i, _i, _i, _d, _d, _p, _p, _i],
     "sv_corners_to_minv": [_p, _i, _i, _f, _p],

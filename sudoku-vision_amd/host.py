@@ -101,3 +101,16 @@ def find_grid_corners_bits_batch(bits, H, W, min_area_ratio=0.1, epsilon_ratio=0
                                                                 corners.ctypes.data_as(C.c_void_p), found.ctypes.data_as(C.c_void_p), int(threads)),
                   "sv_find_grid_corners_bits_batch")
     return corners, found.astype(bool)
+
+
+def solve_sudoku(grid):
+    """grid: 9x9 (or 81) digits, 0 = empty -> (code, solution 9x9 uint8); code 1 solved, 0 no solution, -1 invalid input
+    (the reference solver's SOLVE_* codes).  solution == grid unless solved."""
+    g = np.ascontiguousarray(np.asarray(grid).reshape(81))
+    if g.min() < 0 or g.max() > 255:
+        return -1, np.asarray(grid, np.uint8).reshape(9, 9)
+    g = g.astype(np.uint8)
+    out = np.empty(81, np.uint8)
+    res = C.c_int()
+    _native.check(_native.lib().sv_solve_sudoku(g.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(res)), "sv_solve_sudoku")
+    return res.value, out.reshape(9, 9)

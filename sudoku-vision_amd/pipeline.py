@@ -129,3 +129,11 @@ def recognize_image(image, model_state_dict=None, ctx=None, glue=Context.GLUE_RU
     digits = out["digits"][0].cpu().numpy()
     return {"grid": [[int(digits[r * 9 + c]) for c in range(9)] for r in range(9)], "digits": digits,
             "confidence": out["conf"][0].cpu().numpy(), "logits": out["logits"][0].cpu().numpy(), "corners": corners}
+
+
+def run_solver(grid):
+    """The reference's run_solver (pipeline/run.py:163-202) without the subprocess: -> (success, solution) with
+    solution == grid when the puzzle is invalid or has no solution."""
+    code, sol = host.solve_sudoku(grid)
+    g = [[int(v) for v in row] for row in np.asarray(grid).reshape(9, 9)]
+    return (True, [[int(v) for v in row] for row in sol]) if code == 1 else (False, g)

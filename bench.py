@@ -84,9 +84,13 @@ def main():
     rank, local_rank, world = sharding.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # SV_BENCH_REHEARSE=1: rehearse the multi-rank code path on a one-GPU box (all ranks on cuda:0, gloo instead of RCCL)
+    rehearse = os.environ.get("SV_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    sharding.init("nccl")          # RCCL; only for the timing barrier and the MAX of elapsed
-    dev = torch.device("cuda", local_rank)
+    sharding.init("gloo" if rehearse else "nccl")          # RCCL; only for the timing barrier and the MAX of elapsed
+    dev = None if rehearse else torch.device("cuda", local_rank)
 
     from sudoku_vision_amd.synth import synth_frames
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -110,7 +114,9 @@ def main():
         return binary
 
     def barrier():
+        torch.cuda.synchronize()
         sharding.barrier(dev)
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()

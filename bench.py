@@ -30,6 +30,7 @@ CONV_FLOP_PER_CELL = 451_584 + 7_225_344
 FC_FLOP_PER_CELL = 802_816 + 2_560
 HBM_PEAK = 8.0e12                    # B/s, MI355X_MICROARCH.md
 FP32_MFMA_PEAK = 157.3e12            # FLOP/s, v_mfma_f32_* (= fp32 vector peak)
+BF16_MFMA_PEAK = 2.5e15              # FLOP/s dense, v_mfma_f32_*_bf16
 
 
 def cpu_baseline(frames_host, corners, sd, threads):
@@ -72,6 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (headline); bf16 = configs[4]: conv2/fc1 on bf16 MFMA, digit-index parity only")
     ap.add_argument("--e2e-passes", type=int, default=8, help="passes over the pool with the host corner search in the loop (0 = skip)")
     args = ap.parse_args()
 
@@ -103,6 +106,8 @@ def main():
     sd = cnn_oracle.random_state_dict(1234)        # random-init weights of the DigitCNN architecture
     ctx.load_state_dict(sd)
     ctx.reserve(n * 81)
+    if args.precision == "bf16":
+        ctx.set_precision(ctx.PREC_BF16)
     minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners))
     out = {"logits": torch.empty((n, 81, 10), dtype=torch.float32, device="cuda"),
            "digits": torch.empty((n, 81), dtype=torch.uint8, device="cuda"),
@@ -160,7 +165,7 @@ def main():
                 continue
             bound, units = work[name]
             avg = ms / cnt * 1e-3
-            peak = HBM_PEAK if bound == "hbm" else FP32_MFMA_PEAK
+            peak = HBM_PEAK if bound == "hbm" else (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK)
             ach = units / avg
             kernels[name] = {"bound": bound, "avg_ms": ms / cnt, "launches": cnt,
                              "achieved": ach / (1e9 if bound == "hbm" else 1e12), "peak": peak / (1e9 if bound == "hbm" else 1e12),
@@ -169,7 +174,7 @@ def main():
         # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected
         # as MI355X_MICROARCH.md prescribes; collected on this same command at 256 frames, profiles/pmc_traffic.json)
         traffic, tf = None, os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf) and n == 256:
+        if os.path.exists(tf) and n == 256 and args.precision == "f32":
             pmc = json.load(open(tf))
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
             for k in kernels:
@@ -178,8 +183,8 @@ def main():
         res = {
             "metric": "end-to-end frames/sec (1080p->81 digits)", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {n} synthetic 1080p frames per GPU per step, HIP threshold + warp + 81-cell CNN fp32 forward, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"configs[{1 if args.precision == 'f32' else 4}]: {n} synthetic 1080p frames per GPU per step, HIP threshold + warp + 81-cell CNN {args.precision} forward, "
                                    "generator corners (host corner search not in the timed region)",
                        "frames_per_gpu": n, "height": H, "width": W, "weights": "random-init DigitCNN (seed 1234)",
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},

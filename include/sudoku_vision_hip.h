@@ -57,6 +57,13 @@ const char *sv_last_error(void);                    /* thread-local, never NULL 
 int sv_ctx_create(int device, sv_ctx **out);
 int sv_ctx_destroy(sv_ctx *ctx);
 
+/* Arithmetic of the CNN's conv2/fc1 (BASELINE.json configs[1] vs configs[4]).  SV_PREC_F32 (default): exact f32 MFMA,
+ * logits within 1e-4 of the PyTorch-CPU model.  SV_PREC_BF16: bf16 operands, f32 accumulation (v_mfma_f32_16x16x32_bf16);
+ * parity target = predicted digit indices.  Applies to sv_cnn_forward_cells_u8 and sv_frames_to_digits. */
+#define SV_PREC_F32 0
+#define SV_PREC_BF16 1
+int sv_ctx_set_precision(sv_ctx *ctx, int precision);
+
 /* Pre-sizes the context's scratch for batches of up to `max_cells` cells so that later calls do
  * no hipMalloc (needed before hipGraph capture). */
 int sv_ctx_reserve(sv_ctx *ctx, long max_cells);

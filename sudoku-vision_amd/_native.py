@@ -18,6 +18,7 @@ SIGNATURES = {
     "sv_ctx_create": [_i, C.POINTER(_p)],
     "sv_ctx_destroy": [_p],
     "sv_ctx_reserve": [_p, _l],
+    "sv_ctx_set_precision": [_p, _i],
     "sv_load_weights_f32": [_p, _p],
     "sv_timing_begin": [_p],
     "sv_timing_end": [_p, _p, _p],

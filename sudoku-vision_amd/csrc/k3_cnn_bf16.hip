@@ -1,0 +1,217 @@
+// K3, bf16 configuration (BASELINE.json configs[4]): conv2 and fc1 on v_mfma_f32_16x16x32_bf16 with f32 accumulation.
+// conv1 stays f32 on the VALU and rounds its ReLU/pool output to bf16; weights of conv2/fc1 are rounded to bf16 once on
+// the host.  Parity target for this configuration: predicted digit indices (logits differ from f32 by ~1e-2).
+//
+//   k_conv_features_bf16 : 2 cells per workgroup iteration, 4 waves, 2 workgroups per CU.  conv1 output goes to LDS
+//        channel-last (position-major, 32 bf16 channels = 64 B per position, rows padded to 80 B against bank conflicts)
+//        so that one ds_read_b128 is one MFMA A operand (8 input channels of one 3x3 tap for one output position);
+//        a wave keeps all 9 x 4 B operands (288 x 64 weights) in 144 VGPRs.  36 MFMAs per 16 positions x 64 channels
+//        instead of 288 in f32.  N tiles are interleaved (column c of tile t = channel 4c + t) so that a lane ends up with
+//        4 consecutive channels of one pooled window: one 8-byte store of bf16 features.
+//   k_fc_head_bf16       : fc1 on the same MFMA (K = 3136 = 98 steps), fc2/argmax/softmax epilogue in f32 as in k_fc_head.
+#include "sv_device.h"
+#include "sv_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int POS_STRIDE = 80;                 // bytes per padded position (64 data + 16)
+constexpr int C1B_CELL = 256 * POS_STRIDE;     // 16x16 padded positions
+constexpr int IN_W = 30, IN_CELL = 900;
+constexpr int FEAT = 3136;
+
+__device__ __forceinline__ float glue_norm(u8 c)
+{
+    const float t = __fdiv_rn((float)(255 - (int)c), 255.0f);
+    return __fdiv_rn(__fsub_rn(t, 0.5f), 0.5f);
+}
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+
+__global__ __launch_bounds__(256, 2) void k_conv_features_bf16(const u8 *__restrict__ cells, long B, const float *__restrict__ w1,
+                                                               const float *__restrict__ b1, const uint4 *__restrict__ w2img,
+                                                               const float *__restrict__ b2, unsigned short *__restrict__ feat)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char c1b[2 * C1B_CELL];
+    __shared__ float in_s[2 * IN_CELL];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, q = lane >> 4;
+
+    uint4 breg[9][4];                           // [tap][n tile]: B[k = 8q+j][col c16] = W2[oc = 4*c16 + t][ic = 8q + j][tap]
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) breg[tap][t] = w2img[(tap * 4 + t) * 64 + lane];
+    float bias2[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) bias2[t] = b2[4 * c16 + t];
+
+    for (int i = tid; i < 2 * C1B_CELL / 4; i += 256) ((unsigned *)c1b)[i] = 0;    // zero borders, for good
+    for (int i = tid; i < 2 * IN_CELL; i += 256) in_s[i] = 0.f;
+    __syncthreads();
+
+    const long npairs = (B + 1) / 2;
+    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+        for (int i = tid; i < 2 * 784; i += 256) {
+            const int cl = i / 784, p = i - cl * 784, y = p / 28, x = p - y * 28;
+            long cg = pair * 2 + cl;
+            if (cg >= B) cg = B - 1;
+            in_s[cl * IN_CELL + (y + 1) * IN_W + x + 1] = glue_norm(cells[cg * 784 + p]);
+        }
+        __syncthreads();
+
+        // conv1 + ReLU + pool (f32), output rounded to bf16, channel-last: wave w owns channels 8w..8w+7 = one 16-B store
+        for (int rnd = 0; rnd < 7; rnd++) {
+            const int idx = rnd * 64 + lane;
+            if (idx < 392) {
+                const int cl = idx / 196, pp = idx - cl * 196, py = pp / 14, px = pp - py * 14;
+                float patch[4][4];
+                const float *src = in_s + cl * IN_CELL + (2 * py) * IN_W + 2 * px;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) patch[i][j] = src[i * IN_W + j];
+                unsigned short o8[8];
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    const int oc = wave * 8 + o;
+                    const float *w = w1 + oc * 9;
+                    const float bias = b1[oc];
+                    float m = -3.0e38f;
+#pragma unroll
+                    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                        for (int dx = 0; dx < 2; dx++) {
+                            float acc = bias;
+#pragma unroll
+                            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                                for (int kx = 0; kx < 3; kx++) acc = __builtin_fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
+                            m = fmaxf(m, acc);
+                        }
+                    o8[o] = bf16_bits(fmaxf(m, 0.f));
+                }
+                uint4 v;
+                v.x = o8[0] | ((unsigned)o8[1] << 16); v.y = o8[2] | ((unsigned)o8[3] << 16);
+                v.z = o8[4] | ((unsigned)o8[5] << 16); v.w = o8[6] | ((unsigned)o8[7] << 16);
+                *(uint4 *)(c1b + cl * C1B_CELL + ((py + 1) * 16 + px + 1) * POS_STRIDE + wave * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        // conv2: 25 tiles of 4 pooling windows
+        for (int j = wave; j < 25; j += 4) {
+            int g = 4 * j + (c16 >> 2);
+            if (g > 97) g = 97;
+            const int cl = g >= 49 ? 1 : 0, wl = g - 49 * cl, wy = wl / 7, wx = wl - 7 * wy, s = c16 & 3;
+            const unsigned char *ap = c1b + cl * C1B_CELL + ((2 * wy + (s >> 1)) * 16 + 2 * wx + (s & 1)) * POS_STRIDE + q * 16;
+            f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *(const uint4 *)(ap + ((tap / 3) * 16 + tap % 3) * POS_STRIDE));
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, breg[tap][t]), acc[t], 0, 0, 0);
+            }
+            const int gw = 4 * j + q;                      // rows 4q..4q+3 = the window's 4 positions; column c16 of tile t = channel 4*c16 + t
+            if (gw < 98) {
+                const int ocl = gw >= 49 ? 1 : 0, owl = gw - 49 * ocl;
+                const long cg = pair * 2 + ocl;
+                if (cg < B) {
+                    unsigned short h[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        h[t] = bf16_bits(fmaxf(fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])) + bias2[t], 0.f));
+                    uint2 v;
+                    v.x = h[0] | ((unsigned)h[1] << 16);
+                    v.y = h[2] | ((unsigned)h[3] << 16);
+                    *(uint2 *)(feat + cg * FEAT + owl * 64 + 4 * c16) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fc_head_bf16(const unsigned short *__restrict__ feat, long B, const uint4 *__restrict__ w1img,
+                                                      const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+                                                      float *__restrict__ logits, u8 *__restrict__ digits, float *__restrict__ conf)
+{
+    __shared__ float hs[4][16][129];
+    __shared__ float w2s[10][128];
+    __shared__ float lg[4][16][12];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const long cell0 = (long)blockIdx.x * 64 + wave * 16;
+    long crow = cell0 + r;
+    if (crow >= B) crow = B - 1;
+    const uint4 *ap = (const uint4 *)(feat + crow * FEAT) + q;      // step s: + 4*s
+    const uint4 *bp = w1img + lane;                                 // [98][8][64]
+
+    for (int i = tid; i < 1280; i += 256) w2s[i >> 7][i & 127] = w2[i];
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int s = 0; s < 98; s++) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, ap[4 * s]);
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8, bp[(s * 8 + t) * 64]), acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float bias = b1[16 * t + r];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) hs[wave][4 * q + reg][16 * t + r] = fmaxf(acc[t][reg] + bias, 0.f);
+    }
+    __syncthreads();
+    for (int jj = 0; jj < 3; jj++) {
+        const int j = q + 4 * jj;
+        if (j < 10) {
+            float sacc = b2[j];
+            for (int n = 0; n < 128; n++) sacc = __builtin_fmaf(hs[wave][r][n], w2s[j][n], sacc);
+            lg[wave][r][j] = sacc;
+            if (cell0 + r < B) logits[(cell0 + r) * 10 + j] = sacc;
+        }
+    }
+    __syncthreads();
+    if (q == 0 && cell0 + r < B && (digits || conf)) {
+        float best = lg[wave][r][0];
+        int arg = 0;
+        for (int j = 1; j < 10; j++)
+            if (lg[wave][r][j] > best) { best = lg[wave][r][j]; arg = j; }
+        if (digits) digits[cell0 + r] = (u8)arg;
+        if (conf) {
+            float den = 0.f;
+            for (int j = 0; j < 10; j++) den += expf(lg[wave][r][j] - best);
+            conf[cell0 + r] = 1.0f / den;
+        }
+    }
+}
+
+}  // namespace
+
+int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
+{
+    const sv_weights &w = ctx->w;
+    const long npairs = (B + 1) / 2;
+    const int grid = (int)(npairs < 2L * ctx->num_cus ? npairs : 2L * ctx->num_cus);
+    {
+        sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
+        hipLaunchKernelGGL(k_conv_features_bf16, dim3(grid), dim3(256), 0, s, cells, B, w.conv1_w, w.conv1_b, (const uint4 *)w.conv2_bf16, w.conv2_b,
+                           (unsigned short *)ctx->features);
+    }
+    SV_LAUNCH_CHECK("k_conv_features_bf16");
+    sv_time_scope ts(ctx, SVK_FC_HEAD, s);
+    hipLaunchKernelGGL(k_fc_head_bf16, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, (const unsigned short *)ctx->features, B, (const uint4 *)w.fc1_bf16,
+                       w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
+    SV_LAUNCH_CHECK("k_fc_head_bf16");
+    return SV_OK;
+}

@@ -46,6 +46,9 @@ static void free_weights(sv_weights &w)
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    if (w.conv2_bf16) (void)hipFree(w.conv2_bf16);
+    if (w.fc1_bf16) (void)hipFree(w.fc1_bf16);
+    w.conv2_bf16 = w.fc1_bf16 = nullptr;
     w.loaded = false;
 }
 
@@ -78,6 +81,13 @@ int sv_ensure_scratch(sv_ctx *ctx, long cells)
     SV_HIP(hipMalloc((void **)&ctx->cells, (size_t)SV_CELL_PX * (size_t)cells));
     SV_HIP(hipMalloc((void **)&ctx->cells2, (size_t)SV_CELL_PX * (size_t)cells));
     ctx->cap_cells = cells;
+    return SV_OK;
+}
+
+extern "C" int sv_ctx_set_precision(sv_ctx *ctx, int precision)
+{
+    if (!ctx || (precision != SV_PREC_F32 && precision != SV_PREC_BF16)) return sv_fail(SV_ERR_BAD_ARG, "sv_ctx_set_precision: bad argument");
+    ctx->precision = precision;
     return SV_OK;
 }
 
@@ -167,6 +177,29 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
                     const int kp = 16 * c + 4 * (lane >> 4) + e, win = kp >> 6, oc = kp & 63, n = 16 * t + (lane & 15);
                     f1[(((size_t)c * 8 + t) * 64 + lane) * 4 + e] = f1w[(size_t)n * 3136 + oc * 49 + win];
                 }
+    // bf16 configuration: round-to-nearest-even images for v_mfma_f32_16x16x32_bf16.
+    //   conv2 [tap][t][lane][j]: oc = 4*(lane&15) + t, ic = 8*(lane>>4) + j
+    //   fc1   [step][t][lane][j]: n = 16t + (lane&15), feature k' = 32*step + 8*(lane>>4) + j = window*64 + oc
+    auto bf16 = [](float f) -> uint16_t { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+    std::vector<uint16_t> w2b((size_t)9 * 4 * 64 * 8), fc1b((size_t)98 * 8 * 64 * 8);
+    for (int tap = 0; tap < 9; tap++)
+        for (int t = 0; t < 4; t++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int oc = 4 * (lane & 15) + t, ic = 8 * (lane >> 4) + j;
+                    w2b[(((size_t)tap * 4 + t) * 64 + lane) * 8 + j] = bf16(c2w[(oc * 32 + ic) * 9 + tap]);
+                }
+    for (int st = 0; st < 98; st++)
+        for (int t = 0; t < 8; t++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int kp = 32 * st + 8 * (lane >> 4) + j, win = kp >> 6, oc = kp & 63, n = 16 * t + (lane & 15);
+                    fc1b[(((size_t)st * 8 + t) * 64 + lane) * 8 + j] = bf16(f1w[(size_t)n * 3136 + oc * 49 + win]);
+                }
+    SV_HIP(hipMalloc((void **)&ctx->w.conv2_bf16, w2b.size() * 2));
+    SV_HIP(hipMemcpy(ctx->w.conv2_bf16, w2b.data(), w2b.size() * 2, hipMemcpyHostToDevice));
+    SV_HIP(hipMalloc((void **)&ctx->w.fc1_bf16, fc1b.size() * 2));
+    SV_HIP(hipMemcpy(ctx->w.fc1_bf16, fc1b.data(), fc1b.size() * 2, hipMemcpyHostToDevice));
     int rc;
     if ((rc = upload(&ctx->w.conv1_w, std::vector<float>(c1w, c1w + 288)))) return rc;
     if ((rc = upload(&ctx->w.conv1_b, std::vector<float>(c1b, c1b + 32)))) return rc;
@@ -384,6 +417,15 @@ static int cnn_common(sv_ctx *ctx, const void *x, bool u8in, int glue, long B, f
     int rc = sv_ensure_scratch(ctx, B);
     if (rc) return rc;
     if (glue != SV_GLUE_NORMALIZE && glue != SV_GLUE_RUNPY) return sv_fail(SV_ERR_BAD_ARG, "sv_cnn_forward: glue %d", glue);
+    if (ctx->precision == SV_PREC_BF16) {
+        if (!u8in) return sv_fail(SV_ERR_UNSUPPORTED, "sv_cnn_forward_f32: the bf16 configuration takes 8-bit cells (sv_cnn_forward_cells_u8 / sv_frames_to_digits)");
+        const uint8_t *c = (const uint8_t *)x;
+        if (glue == SV_GLUE_RUNPY) {
+            if ((rc = svk_preprocess_cells(c, B, ctx->cells2, S(stream)))) return rc;
+            c = ctx->cells2;
+        }
+        return svk_cnn_forward_bf16(ctx, c, B, logits, digits, conf, S(stream));
+    }
     return svk_cnn_forward(ctx, x, u8in, glue, B, logits, digits, conf, S(stream));
 }
 
@@ -428,6 +470,5 @@ extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, in
     if (rc) return rc;
     uint8_t *c = cells ? cells : ctx->cells;
     if ((rc = svk_warp_cells(ctx, frames, n, H, W, pitch, frame_stride, minv, c, S(stream)))) return rc;
-    if (glue != SV_GLUE_NORMALIZE && glue != SV_GLUE_RUNPY) return sv_fail(SV_ERR_BAD_ARG, "sv_frames_to_digits: glue %d", glue);
-    return svk_cnn_forward(ctx, c, true, glue, B, logits, digits, conf, S(stream));
+    return cnn_common(ctx, c, true, glue, B, logits, digits, conf, stream);
 }

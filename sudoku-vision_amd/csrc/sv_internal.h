@@ -18,6 +18,8 @@ struct sv_weights {
     float *conv2_b = nullptr;   // [64]
     float *fc1_wreg = nullptr;  // [196 chunk][8 t][64 lane][4 e] MFMA B-operand register image
     float *fc1_b = nullptr;     // [128]
+    unsigned short *conv2_bf16 = nullptr; // [9 tap][4 t][64 lane][8] bf16 MFMA B image (bf16 configuration)
+    unsigned short *fc1_bf16 = nullptr;   // [98 step][8 t][64 lane][8] bf16
     float *fc2_w = nullptr;     // [10][128]
     float *fc2_b = nullptr;     // [10]
     bool loaded = false;
@@ -32,6 +34,7 @@ struct sv_ctx {
     u8 *cells = nullptr;        // [cells][784]
     u8 *cells2 = nullptr;       // [cells][784] preprocess_cell output (SV_GLUE_RUNPY)
     long cap_cells = 0;
+    int precision = 0;          // SV_PREC_F32 / SV_PREC_BF16 (sv_ctx_set_precision)
     // optional per-kernel timing (sv_timing_begin/sv_timing_end): hipEvents on the launch stream
     bool timing = false;
     struct timed { int kernel; hipEvent_t t0, t1; };
@@ -81,6 +84,7 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
 
 int svk_despeckle(const u8 *src, int n, int H, int W, u8 *dst, unsigned *packed, hipStream_t s);
 int svk_resize_linear(const u8 *src, int sh, int sw, ptrdiff_t pitch, u8 *dst, int dh, int dw, hipStream_t s);
+int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8 *digits, float *conf, hipStream_t s);
 int svk_cell_ink_ratio(const u8 *cells, long B, int npx, float *ratio, int *otsu, hipStream_t s);
 int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s);
 

@@ -62,6 +62,12 @@ class Context:
         _native.check(_native.lib().sv_load_weights_f32(self._h, blob.ctypes.data_as(C.c_void_p)), "sv_load_weights_f32")
         self._weights_key = key
 
+    PREC_F32, PREC_BF16 = 0, 1
+
+    def set_precision(self, precision):
+        """PREC_F32 (default, logits within 1e-4 of the reference model) or PREC_BF16 (bf16 MFMA, digit-index parity)."""
+        _native.check(_native.lib().sv_ctx_set_precision(self._h, int(precision)), "sv_ctx_set_precision")
+
     def reserve(self, max_cells):
         _native.check(_native.lib().sv_ctx_reserve(self._h, int(max_cells)), "sv_ctx_reserve")
 

@@ -360,3 +360,32 @@ def test_despeckle_preserves_grid_search(ctx):
         for mar in (0.1, 0.02):
             a, c = sva.host.find_grid_corners(img, mar), sva.host.find_grid_corners(fi, mar)
             assert (a is None) == (c is None) and (a is None or (a == c).all())
+
+
+def test_bf16_configuration_digit_parity(golden_dir):
+    """BASELINE configs[4]: bf16 MFMA conv2/fc1.  Parity target = digit indices; logits are compared loosely."""
+    import sudoku_vision_amd as sva
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    c = sva.Context()
+    c.load_state_dict(sd)
+    c.set_precision(c.PREC_BF16)
+    frames, corners, _ = _frames(3, 540, 960, seed=61)
+    cells = np.concatenate([o.warp_cells(f, cc) for f, cc in zip(frames.cpu().numpy(), corners)] +
+                           [np.random.RandomState(5).randint(0, 256, (77, 28, 28)).astype(np.uint8)])
+    for glue, x in ((0, o.cells_to_input(cells)), (1, o.cells_to_input(o.preprocess_cells(cells)))):
+        logits, digits, conf = c.cnn_forward(torch.from_numpy(cells).cuda(), want_digits=True, glue=glue)
+        el, ed, ec = cnn_oracle.predict(sd, x[:, None])
+        err = np.abs(logits.cpu().numpy() - el.numpy())
+        assert err.max() < 0.5 and err.mean() < 0.03, (err.max(), err.mean())
+        top2 = np.sort(el.numpy(), 1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 4 * err.max()
+        assert clear.mean() > 0.7
+        assert (digits.cpu().numpy()[clear] == ed.numpy()[clear]).all()
+        assert (digits.cpu().numpy() == ed.numpy()).mean() > 0.97
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_UNSUPPORTED"):
+        c.cnn_forward(torch.zeros((2, 1, 28, 28), device="cuda"))
+    c.set_precision(c.PREC_F32)                       # and back: exact path again
+    logits = c.cnn_forward(torch.from_numpy(cells).cuda())
+    assert np.abs(logits.cpu().numpy() - cnn_oracle.forward(sd, o.cells_to_input(cells)[:, None]).numpy()).max() <= LOGIT_TOL
+    c.close()

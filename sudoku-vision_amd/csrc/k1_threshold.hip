@@ -365,34 +365,35 @@ __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__
         }
     };
 
-    // prime: h rows qs-2 .. qs+1, and PF further image rows in flight
-    constexpr int PF = 4;
-    f32x4_t h0, h1 = hrow(load_raw(qs - 2)), h2 = hrow(load_raw(qs - 1)), h3 = hrow(load_raw(qs)), h4 = hrow(load_raw(qs + 1));
+    // Rings with static slots: the row loop is unrolled x12 (12 = lcm of the ring periods), so "which register holds row r"
+    // is a compile-time fact and no window is ever shifted: 12-slot ring of f32 row-pass results (11 in use), 6-slot ring of
+    // h rows (5 in use), PF = 4 image rows in flight.
+    constexpr int PF = 4, NPH = 12;
+    f32x4_t hw[6];
+    hw[2] = hrow(load_raw(qs - 2)); hw[3] = hrow(load_raw(qs - 1)); hw[4] = hrow(load_raw(qs)); hw[5] = hrow(load_raw(qs + 1));
+    hw[0] = hw[2]; hw[1] = hw[2];
     u32x3 raw[PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) raw[i] = load_raw(qs + 2 + i);
 
     f32x4_t cur_rw = {0.f, 0.f, 0.f, 0.f}, cur_bf = {0.f, 0.f, 0.f, 0.f};
-    f32x4_t win[11];
+    f32x4_t win[NPH];
 
-    for (int base = 0; base < N; base += 11) {
+    for (int base = 0; base < N; base += NPH) {
 #pragma unroll
-        for (int ph = 0; ph < 11; ph++) {
+        for (int ph = 0; ph < NPH; ph++) {
             const int i = base + ph;
             if (i < N) {
                 const int q = qs + i;                            // blurred row of this push (rows > H-1 repeat row H-1)
-                const u32x3 raw_cur = raw[0];
-#pragma unroll
-                for (int k = 0; k + 1 < PF; k++) raw[k] = raw[k + 1];
-                raw[PF - 1] = load_raw(q + 2 + PF < H + 2 ? q + 2 + PF : H + 1);   // row that push i + PF will consume
-                h0 = h1; h1 = h2; h2 = h3; h3 = h4;
-                h4 = hrow(raw_cur);
+                const u32x3 raw_cur = raw[ph % PF];
+                raw[ph % PF] = load_raw(q + 2 + PF < H + 2 ? q + 2 + PF : H + 1);   // row that push i + PF will consume
+                hw[ph % 6] = hrow(raw_cur);                      // h row q+2; rows q-2 .. q+1 sit in the 4 slots before it
                 f32x4_t nbf, nrw;
-                finish_row(h0, h1, h2, h3, h4, nbf, nrw);
+                finish_row(hw[(ph + 2) % 6], hw[(ph + 3) % 6], hw[(ph + 4) % 6], hw[(ph + 5) % 6], hw[ph % 6], nbf, nrw);
                 if (q <= H - 1) { cur_bf = nbf; cur_rw = nrw; }   // (a select, not a branch: bottom REPLICATE pushes the last row again)
                 if (i == 0) {
 #pragma unroll
-                    for (int k = 0; k < 11; k++) win[k] = cur_rw;   // top REPLICATE: rows above the first one read the first one
+                    for (int k = 0; k < NPH; k++) win[k] = cur_rw;   // top REPLICATE: rows above the first one read the first one
                 }
                 win[ph] = cur_rw;
                 sdl[wave][i & 7][lane] = cur_bf;
@@ -402,10 +403,10 @@ __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__
                     u32 o = 0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        float acc = __fmul_rn(taps.k[5], win[(ph + 6) % 11][c]);
+                        float acc = __fmul_rn(taps.k[5], win[(ph + NPH - 5) % NPH][c]);
 #pragma unroll
                         for (int j = 1; j <= 5; j++)
-                            acc = __builtin_fmaf(__fadd_rn(win[(ph + 6 + j) % 11][c], win[(ph + 6 + 11 - j) % 11][c]), taps.k[5 + j], acc);
+                            acc = __builtin_fmaf(__fadd_rn(win[(ph + NPH - 5 + j) % NPH][c], win[(ph + 2 * NPH - 5 - j) % NPH][c]), taps.k[5 + j], acc);
                         o |= (__fsub_rn(rintf(acc), srcv[c]) >= 2.f ? 255u : 0u) << (8 * c);
                     }
                     if (lane >= 2 && lane < 62 && cx0 < W) *(u32 *)(dst + (ptrdiff_t)yo * W + cx0) = o;

@@ -1,6 +1,8 @@
 // K3 -- DigitCNN.forward (ml/model.py:34-42, eval mode) on MI355X, fp32 throughout.
 //
-//   k_conv_features_pc : persistent, one 512-thread workgroup per CU working through PAIRS of cells.
+//   k_conv_features_wstream : the default conv kernel (Winograd, see its header below).
+//   k_conv_features_pc : the direct form, kept as an independent cross-check (SV_CONV_ALGO=0): persistent, one
+//        512-thread workgroup per CU working through PAIRS of cells.
 //        conv1 (1->32, 3x3, pad 1) + ReLU + 2x2 max-pool on the VALU into zero-bordered 16x16
 //        planes in LDS; conv2 (32->64) as an implicit GEMM on v_mfma_f32_16x16x4_f32:
 //        M = 4 pooling windows x 4 positions, N = 16 output channels, K = 4 input channels of one
@@ -17,6 +19,7 @@
 // per-lane register order the kernels load.
 #include "sv_device.h"
 #include "sv_internal.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -276,6 +279,184 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_pc(const void *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_conv_features_wstream (the default): conv2 by Winograd F(2x2, 3x3), streamed.  The 7x7 grid of 2x2 output tiles of
+// the 14x14 map IS the grid of pooling windows, so per tile:  V = B^T d B over 32 input channels (VALU, 32 add/sub),
+// 16 independent GEMMs  M[xi] = V[xi] (tiles x 32) * U[xi] (32 x 64)  on v_mfma_f32_16x16x4_f32, and
+// Y = A^T M A + bias, ReLU, 2x2 max -- all four outputs of a tile live in the lane that owns (tile, channel), because
+// the 16 GEMMs of one (M tile, N tile) accumulate into 16 register quads of the same lanes.  1568 MFMAs per cell
+// instead of 3600; U (G g G^T, 16 x 32 x 16 per wave) stays in 128 VGPRs.  A workgroup owns a contiguous run of cells
+// and treats their 49-tile grids as ONE sequence of tiles cut into M tiles of 16 (no 49 -> 64 padding; a per-cell
+// variant wasted 23 % of the MFMA rows and needed all of a cell's V, 106 KB, in LDS; here V is two 32-KB slots).
+// Winograd reorders the f32 sums: logits differ from the direct kernel by ~1e-6, inside the 1e-4 tolerance
+// (tests/test_gpu_parity.py::test_conv_algorithms_agree).
+//   step m:  waves 0-3 (one N tile each): 16 GEMMs x 8 k-steps on V[m & 1] for M tile m, output transform, store
+//            waves 4-7: B^T d B of M tile m+1 into V[(m+1) & 1] (512 (channel, tile) items = 2 per thread),
+//                       conv1 of the next cell whose tiles come up (c1 planes double-buffered by cell parity),
+//                       28x28 input of the cell after that (double-buffered too);  one barrier per step.
+// The schedule's hazards (a plane is never overwritten while tiles of its previous cell are still to be transformed,
+// and so on) are checked exhaustively in tests/test_abi.py::test_winograd_stream_schedule.
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ inline long wstream_need(long m, long ncell)   // last cell that M tile m+2 touches
+{
+    const long c = (16 * (m + 2) + 15) / 49;
+    return c < ncell - 1 ? c : ncell - 1;
+}
+
+template <bool U8IN>
+__global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__restrict__ xin, long B, long cells_per_wg,
+                                                                  const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                  const float *__restrict__ ureg_img, const float *__restrict__ b2,
+                                                                  float *__restrict__ feat)
+{
+    constexpr int VSLOT = 16 * 32 * 16;       // [xi][ic][tile]
+    __shared__ __attribute__((aligned(16))) float lds[2 * IN_CELL + 2 * C1_CELL + 2 * VSLOT];
+    float *in_base = lds, *c1_base = lds + 2 * IN_CELL, *v_base = lds + 2 * IN_CELL + 2 * C1_CELL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int nt = wave & 3, ptid = tid & 255;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    const long c0 = (long)blockIdx.x * cells_per_wg;
+    long ncell = B - c0;
+    if (ncell > cells_per_wg) ncell = cells_per_wg;
+    if (ncell <= 0) return;
+    const long ntiles = ncell * 49, NM = (ntiles + 15) / 16;
+
+    float ureg[16][8];
+    float bias2 = 0.f;
+    if (consumer) {
+#pragma unroll
+        for (int xi = 0; xi < 16; xi++)
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) ureg[xi][ks] = ureg_img[((nt * 16 + xi) * 8 + ks) * 64 + lane];
+        bias2 = b2[16 * nt + r16];
+    }
+    for (int i = tid; i < 2 * IN_CELL + 2 * C1_CELL + 2 * VSLOT; i += 512) lds[i] = 0.f;
+    __syncthreads();
+
+    auto stage = [&](long c) {                // producers (256 threads): input of local cell c -> in_s[c & 1]
+        float *in_s = in_base + (c & 1) * IN_CELL;
+        for (int i = ptid; i < 784; i += 256) {
+            const int y = i / 28, x = i - y * 28;
+            float v;
+            if (U8IN) v = glue_norm(((const u8 *)xin)[(c0 + c) * 784 + i]);
+            else v = ((const float *)xin)[(c0 + c) * 784 + i];
+            in_s[(y + 1) * IN_W + x + 1] = v;
+        }
+    };
+    auto conv1 = [&](long c) {                // producers: in_s[c & 1] -> c1[c & 1]
+        const float *in_s = in_base + (c & 1) * IN_CELL;
+        float *c1 = c1_base + (c & 1) * C1_CELL;
+        for (int it = ptid; it < 196 * 8; it += 256) {
+            const int og = it / 196, pp = it - og * 196, py = pp / 14, px = pp - py * 14;
+            float patch[4][4];
+            const float *src = in_s + (2 * py) * IN_W + 2 * px;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) patch[i][j] = src[i * IN_W + j];
+            float *dstp = c1 + (py + 1) * 16 + px + 1;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int oc = og * 4 + o;
+                const float *w = w1 + oc * 9;
+                const float bias = b1[oc];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                    for (int dx = 0; dx < 2; dx++) {
+                        float acc = bias;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                            for (int kx = 0; kx < 3; kx++) acc = __builtin_fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
+                        mx = fmaxf(mx, acc);
+                    }
+                dstp[oc * PLANE] = fmaxf(mx, 0.f);
+            }
+        }
+    };
+    auto transform = [&](long m) {            // producers: V[m & 1] = B^T d B for the 16 tiles of M tile m
+        float *Vs = v_base + (m & 1) * VSLOT;
+        for (int it = ptid; it < 512; it += 256) {
+            const int ic = it >> 4, tl = it & 15;
+            long T = 16 * m + tl;
+            if (T > ntiles - 1) T = ntiles - 1;
+            const long c = T / 49;
+            const int t = (int)(T - 49 * c), wy = t / 7, wx = t - 7 * wy;
+            const float *d = c1_base + (c & 1) * C1_CELL + ic * PLANE + (2 * wy) * 16 + 2 * wx;
+            float tt[4][4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const float d0 = d[x], d1 = d[16 + x], d2 = d[32 + x], d3 = d[48 + x];
+                tt[0][x] = d0 - d2; tt[1][x] = d1 + d2; tt[2][x] = d2 - d1; tt[3][x] = d1 - d3;
+            }
+            float *vp = Vs + it;              // (xi*32 + ic)*16 + tl = xi*512 + it
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                vp[(y * 4 + 0) * 512] = tt[y][0] - tt[y][2];
+                vp[(y * 4 + 1) * 512] = tt[y][1] + tt[y][2];
+                vp[(y * 4 + 2) * 512] = tt[y][2] - tt[y][1];
+                vp[(y * 4 + 3) * 512] = tt[y][1] - tt[y][3];
+            }
+        }
+    };
+
+    // prologue
+    long conv_done = ncell > 1 ? 1 : 0, staged = conv_done;
+    if (!consumer) { stage(0); if (ncell > 1) stage(1); }
+    __syncthreads();
+    if (!consumer) { conv1(0); if (ncell > 1) conv1(1); }
+    __syncthreads();
+    if (!consumer) transform(0);
+    __syncthreads();
+
+    for (long m = 0; m < NM; m++) {
+        if (consumer) {
+            const float *ap = v_base + (m & 1) * VSLOT + q * 16 + r16;
+            f32x4 acc[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; xi++) acc[xi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // k-step outermost: consecutive MFMAs hit 16 different accumulators (a dependent 16x16x4 f32 MFMA needs 40
+            // cycles, an independent one issues every 32)
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+                for (int xi = 0; xi < 16; xi++)
+                    acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(xi * 32 + 4 * ks) * 16], ureg[xi][ks], acc[xi], 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const long T = 16 * m + 4 * q + reg;
+                float s0[4], s1[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const float m0 = acc[x][reg], m1 = acc[4 + x][reg], m2 = acc[8 + x][reg], m3 = acc[12 + x][reg];
+                    s0[x] = m0 + m1 + m2;
+                    s1[x] = m1 - m2 - m3;
+                }
+                const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+                const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+                const float pooled = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias2, 0.f);
+                if (T < ntiles) {
+                    const long c = T / 49;
+                    feat[(c0 + c) * FEAT + (T - 49 * c) * 64 + 16 * nt + r16] = pooled;
+                }
+            }
+        } else {
+            if (m + 1 < NM) transform(m + 1);
+            const long cc = wstream_need(m, ncell);
+            if (cc > conv_done) { conv1(cc); conv_done = cc; }
+            const long sc = wstream_need(m + 1, ncell);
+            if (sc > staged) { stage(sc); staged = sc; }
+        }
+        __syncthreads();
+    }
+}
+
 // 64 cells per workgroup, 16 per wave; K = 3136 in 196 chunks of 16.
 __global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat, long B, const float *__restrict__ w1reg,
                                                  const float *__restrict__ b1, const float *__restrict__ w2,
@@ -396,7 +577,17 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
         if (rc) return rc;
         x = ctx->cells2;
     }
-    {
+    static const int conv_algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 2;     // cross-check aid: 0 = direct implicit GEMM (k_conv_features_pc), 2 = Winograd stream
+    if (conv_algo == 2) {
+        long cpw = (B + ctx->num_cus - 1) / ctx->num_cus;
+        if (cpw < 1) cpw = 1;
+        const int grid_s = (int)((B + cpw - 1) / cpw);
+        sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
+        if (x_is_u8)
+            hipLaunchKernelGGL(k_conv_features_wstream<true>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, w.conv2_wino, w.conv2_b, ctx->features);
+        else
+            hipLaunchKernelGGL(k_conv_features_wstream<false>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, w.conv2_wino, w.conv2_b, ctx->features);
+    } else {
         const int grid_pc = (int)(npairs < (long)ctx->num_cus ? npairs : (long)ctx->num_cus);
         sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
         if (x_is_u8)

@@ -41,7 +41,7 @@ extern "C" int sv_ctx_create(int device, sv_ctx **out)
 
 static void free_weights(sv_weights &w)
 {
-    float **ps[] = {&w.conv1_w, &w.conv1_b, &w.conv2_wreg, &w.conv2_b, &w.fc1_wreg, &w.fc1_b, &w.fc2_w, &w.fc2_b};
+    float **ps[] = {&w.conv1_w, &w.conv1_b, &w.conv2_wreg, &w.conv2_wino, &w.conv2_b, &w.fc1_wreg, &w.fc1_b, &w.fc2_w, &w.fc2_b};
     for (float **p : ps) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -177,6 +177,22 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
                     const int kp = 16 * c + 4 * (lane >> 4) + e, win = kp >> 6, oc = kp & 63, n = 16 * t + (lane & 15);
                     f1[(((size_t)c * 8 + t) * 64 + lane) * 4 + e] = f1w[(size_t)n * 3136 + oc * 49 + win];
                 }
+    // Winograd F(2x2,3x3) weights U = G g G^T (computed in double), as [nt][xi][ks][lane]: oc = 16nt + (lane&15), ic = 4ks + (lane>>4)
+    std::vector<float> wino((size_t)4 * 16 * 8 * 64);
+    {
+        const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        for (int oc = 0; oc < 64; oc++)
+            for (int ic = 0; ic < 32; ic++) {
+                const float *g = c2w + (oc * 32 + ic) * 9;
+                double Gg[4][3], U[4][4];
+                for (int i = 0; i < 4; i++)
+                    for (int j = 0; j < 3; j++) Gg[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+                for (int i = 0; i < 4; i++)
+                    for (int j = 0; j < 4; j++) U[i][j] = Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2];
+                const int nt = oc >> 4, lane = (oc & 15) + 16 * (ic & 3), ks = ic >> 2;
+                for (int xi = 0; xi < 16; xi++) wino[(((size_t)nt * 16 + xi) * 8 + ks) * 64 + lane] = (float)U[xi >> 2][xi & 3];
+            }
+    }
     // bf16 configuration: round-to-nearest-even images for v_mfma_f32_16x16x32_bf16.
     //   conv2 [tap][t][lane][j]: oc = 4*(lane&15) + t, ic = 8*(lane>>4) + j
     //   fc1   [step][t][lane][j]: n = 16t + (lane&15), feature k' = 32*step + 8*(lane>>4) + j = window*64 + oc
@@ -204,6 +220,7 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
     if ((rc = upload(&ctx->w.conv1_w, std::vector<float>(c1w, c1w + 288)))) return rc;
     if ((rc = upload(&ctx->w.conv1_b, std::vector<float>(c1b, c1b + 32)))) return rc;
     if ((rc = upload(&ctx->w.conv2_wreg, w2))) return rc;
+    if ((rc = upload(&ctx->w.conv2_wino, wino))) return rc;
     if ((rc = upload(&ctx->w.conv2_b, std::vector<float>(c2b, c2b + 64)))) return rc;
     if ((rc = upload(&ctx->w.fc1_wreg, f1))) return rc;
     if ((rc = upload(&ctx->w.fc1_b, std::vector<float>(f1b, f1b + 128)))) return rc;

@@ -15,6 +15,7 @@ struct sv_weights {
     float *conv1_w = nullptr;   // [32][9]
     float *conv1_b = nullptr;   // [32]
     float *conv2_wreg = nullptr;// [2 np][2 t][72 ks][64 lane]  MFMA B-operand register image
+    float *conv2_wino = nullptr;// [4 nt][16 xi][8 ks][64 lane]  Winograd U = G g G^T as MFMA B-operand image
     float *conv2_b = nullptr;   // [64]
     float *fc1_wreg = nullptr;  // [196 chunk][8 t][64 lane][4 e] MFMA B-operand register image
     float *fc1_b = nullptr;     // [128]

@@ -389,3 +389,28 @@ def test_bf16_configuration_digit_parity(golden_dir):
     logits = c.cnn_forward(torch.from_numpy(cells).cuda())
     assert np.abs(logits.cpu().numpy() - cnn_oracle.forward(sd, o.cells_to_input(cells)[:, None]).numpy()).max() <= LOGIT_TOL
     c.close()
+
+
+def test_conv_algorithms_agree(golden_dir):
+    """Two independent conv2 implementations -- Winograd stream (default) and direct implicit GEMM (SV_CONV_ALGO=0) -- give
+    the same logits to ~1e-5 and the same digits; run in a subprocess because the choice is read once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, numpy as np, torch\n"
+            f"sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'oracle'))\n"
+            "import sudoku_vision_amd as sva, cnn_oracle\n"
+            f"g = np.load(os.path.join({golden_dir!r}, 'cnn_coreml_fp16.npz'))\n"
+            "sd = {k: torch.from_numpy(g[k.replace('.', '_')].astype(np.float32)) for k in cnn_oracle.KEYS}\n"
+            "ctx = sva.default_context(); ctx.load_state_dict(sd)\n"
+            "x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (500, 28, 28)).astype(np.uint8)).cuda()\n"
+            "np.save(sys.argv[1], ctx.cnn_forward(x).cpu().numpy())\n")
+    outs = []
+    for algo in ("2", "0"):
+        path = f"/tmp/sv_conv_algo_{algo}.npy"
+        env = dict(os.environ, SV_CONV_ALGO=algo)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-5
+    assert (outs[0].argmax(1) == outs[1].argmax(1)).all()

@@ -83,3 +83,34 @@ def test_dropin_module_names_resolve():
             "print('ok')") % (os.path.join(ROOT, "sudoku-vision_amd", "cv"), os.path.join(ROOT, "sudoku-vision_amd", "ml"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_winograd_stream_schedule():
+    """The producer schedule of k_conv_features_wstream (csrc/k3_cnn.hip): checked exhaustively for every run length a
+    workgroup can get.  Invariants: a tile is transformed only after its cell's conv1; conv1(c) finds its input staged;
+    a conv1 plane (double-buffered by cell parity) is never overwritten while tiles of the cell it held are still to be
+    transformed in the same step; staging never writes the input buffer conv1 is reading."""
+    def need(m, ncell):
+        return min(ncell - 1, (16 * (m + 2) + 15) // 49)
+    for ncell in list(range(1, 200)) + [1000]:
+        nm = (ncell * 49 + 15) // 16
+        conv_done = staged = min(1, ncell - 1)
+        assert min(ncell - 1, 15 // 49) <= conv_done                       # M tile 0 (prologue transform)
+        for m in range(nm):
+            read_cells = set()
+            if m + 1 < nm:
+                lo, hi = (16 * (m + 1)) // 49, min(ncell - 1, (16 * (m + 1) + 15) // 49)
+                assert hi <= conv_done
+                read_cells = set(range(lo, hi + 1))
+            cc = need(m, ncell)
+            if cc > conv_done:
+                assert cc == conv_done + 1 and cc <= staged
+                assert (cc - 2) not in read_cells
+                conv_done = cc
+            sc = need(m + 1, ncell)
+            if sc > staged:
+                assert sc == staged + 1
+                assert sc - 2 <= conv_done and not (cc == conv_done and (sc & 1) == (cc & 1) and sc != cc and cc > staged)
+                assert (sc & 1) != (cc & 1) or sc == cc
+                staged = sc
+        assert conv_done == ncell - 1

@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -352,31 +353,30 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
         float *c1 = c1_base + (c & 1) * C1_CELL;
         for (int it = ptid; it < 196 * 8; it += 256) {
             const int og = it / 196, pp = it - og * 196, py = pp / 14, px = pp - py * 14;
-            float patch[4][4];
+            // the 4x4 input patch as overlapping horizontal pairs: one v_pk_fma_f32 does the two outputs of a pooling-window
+            // row (this wave issues almost alone on its SIMD, where a packed FMA costs barely more than a plain one)
+            f32x2 pr[4][3];
             const float *src = in_s + (2 * py) * IN_W + 2 * px;
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) patch[i][j] = src[i * IN_W + j];
+                for (int j = 0; j < 3; j++) pr[i][j] = (f32x2){src[i * IN_W + j], src[i * IN_W + j + 1]};
             float *dstp = c1 + (py + 1) * 16 + px + 1;
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 const int oc = og * 4 + o;
                 const float *w = w1 + oc * 9;
                 const float bias = b1[oc];
-                float mx = -3.0e38f;
+                f32x2 a0 = {bias, bias}, a1 = {bias, bias};          // output rows dy = 0, 1; lanes = dx 0, 1
 #pragma unroll
-                for (int dy = 0; dy < 2; dy++)
+                for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-                    for (int dx = 0; dx < 2; dx++) {
-                        float acc = bias;
-#pragma unroll
-                        for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                            for (int kx = 0; kx < 3; kx++) acc = __builtin_fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
-                        mx = fmaxf(mx, acc);
+                    for (int kx = 0; kx < 3; kx++) {
+                        const f32x2 wv = {w[ky * 3 + kx], w[ky * 3 + kx]};
+                        a0 = __builtin_elementwise_fma(wv, pr[ky][kx], a0);
+                        a1 = __builtin_elementwise_fma(wv, pr[ky + 1][kx], a1);
                     }
-                dstp[oc * PLANE] = fmaxf(mx, 0.f);
+                dstp[oc * PLANE] = fmaxf(fmaxf(fmaxf(a0[0], a0[1]), fmaxf(a1[0], a1[1])), 0.f);
             }
         }
     };

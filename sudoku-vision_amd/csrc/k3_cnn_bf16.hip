@@ -13,6 +13,7 @@
 #include "sv_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
@@ -68,30 +69,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_features_bf16(const u8 *__restr
             const int idx = rnd * 64 + lane;
             if (idx < 392) {
                 const int cl = idx / 196, pp = idx - cl * 196, py = pp / 14, px = pp - py * 14;
-                float patch[4][4];
+                f32x2 pr[4][3];                 // overlapping horizontal pairs of the 4x4 patch: one v_pk_fma_f32 = two outputs
                 const float *src = in_s + cl * IN_CELL + (2 * py) * IN_W + 2 * px;
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) patch[i][j] = src[i * IN_W + j];
+                    for (int j = 0; j < 3; j++) pr[i][j] = (f32x2){src[i * IN_W + j], src[i * IN_W + j + 1]};
                 unsigned short o8[8];
 #pragma unroll
                 for (int o = 0; o < 8; o++) {
                     const int oc = wave * 8 + o;
                     const float *w = w1 + oc * 9;
                     const float bias = b1[oc];
-                    float m = -3.0e38f;
+                    f32x2 a0 = {bias, bias}, a1 = {bias, bias};
 #pragma unroll
-                    for (int dy = 0; dy < 2; dy++)
+                    for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-                        for (int dx = 0; dx < 2; dx++) {
-                            float acc = bias;
-#pragma unroll
-                            for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                                for (int kx = 0; kx < 3; kx++) acc = __builtin_fmaf(w[ky * 3 + kx], patch[dy + ky][dx + kx], acc);
-                            m = fmaxf(m, acc);
+                        for (int kx = 0; kx < 3; kx++) {
+                            const f32x2 wv = {w[ky * 3 + kx], w[ky * 3 + kx]};
+                            a0 = __builtin_elementwise_fma(wv, pr[ky][kx], a0);
+                            a1 = __builtin_elementwise_fma(wv, pr[ky + 1][kx], a1);
                         }
+                    const float m = fmaxf(fmaxf(a0[0], a0[1]), fmaxf(a1[0], a1[1]));
                     o8[o] = bf16_bits(fmaxf(m, 0.f));
                 }
                 uint4 v;

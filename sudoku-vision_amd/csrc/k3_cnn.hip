@@ -541,6 +541,119 @@ __global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_fc_head_frame: one 512-thread workgroup per 81 cells (one frame), i.e. one per CU at 256 frames, so the MFMA work is
+// spread evenly, and the fc1 weight image is fetched ONCE per workgroup: each 32-wide K stage (16 KB) goes global ->
+// registers -> LDS (double-buffered, one barrier per stage) and all waves read their B operands from LDS.  The plain
+// k_fc_head streams the whole 1.6 MB image through every wave and is bound by L1 bandwidth (and by 324 workgroups on 256 CUs).
+// 81 cells = 6 M tiles: waves 0-3 take M tiles 0-3 (all 8 N tiles), waves 4-7 take M tiles 4,5 split in two halves of N,
+// which gives every SIMD (waves s and s+4) three half-tile jobs.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_fc_head_frame(const float *__restrict__ feat, long B, const float *__restrict__ w1reg,
+                                                       const float *__restrict__ b1, const float *__restrict__ w2,
+                                                       const float *__restrict__ b2, float *__restrict__ logits,
+                                                       u8 *__restrict__ digits, float *__restrict__ conf)
+{
+    constexpr int CELLS = 81, ROWS = 96, CH = 2;                      // cells per workgroup, padded rows, 16-wide chunks per stage
+    __shared__ __attribute__((aligned(16))) f32x4 wt[2][CH * 8 * 64]; // 2 x 16 KB weight stages
+    __shared__ float hs[ROWS][129];
+    __shared__ float w2s[10][128];
+    __shared__ float lg[ROWS][12];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int mt = wave < 4 ? wave : 4 + ((wave - 4) >> 1);           // M tile of this wave
+    const int t0 = wave < 4 ? 0 : 4 * ((wave - 4) & 1);               // first N tile
+    const int nt_cnt = wave < 4 ? 8 : 4;                              // N tiles of this wave
+    const long cellbase = (long)blockIdx.x * CELLS;
+    long crow = cellbase + mt * 16 + r;
+    const long last = (cellbase + CELLS < B ? cellbase + CELLS : B) - 1;
+    if (crow > last) crow = last;
+    const f32x4 *ap = (const f32x4 *)(feat + crow * FEAT + 4 * q);
+    const f32x4 *wp = (const f32x4 *)w1reg;                           // [196][8][64] float4
+
+    for (int i = tid; i < 1280; i += 512) w2s[i >> 7][i & 127] = w2[i];
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NSTAGE = 196 / CH;                                  // 98 stages of 1024 float4 = 2 per thread
+    f32x4 wreg[2], areg[CH];
+    wreg[0] = wp[tid]; wreg[1] = wp[512 + tid];
+#pragma unroll
+    for (int c = 0; c < CH; c++) areg[c] = ap[c * 4];
+    wt[0][tid] = wreg[0]; wt[0][512 + tid] = wreg[1];
+    __syncthreads();
+
+    for (int st = 0; st < NSTAGE; st++) {
+        const int cur = st & 1;
+        f32x4 a[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) a[c] = areg[c];
+        if (st + 1 < NSTAGE) {                                        // next stage: global -> registers while this one computes
+            wreg[0] = wp[(long)(st + 1) * 1024 + tid];
+            wreg[1] = wp[(long)(st + 1) * 1024 + 512 + tid];
+#pragma unroll
+            for (int c = 0; c < CH; c++) areg[c] = ap[((st + 1) * CH + c) * 4];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            if (nt_cnt == 8) {
+                f32x4 b[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) b[t] = wt[cur][(c * 8 + t) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][e], b[t][e], acc[t], 0, 0, 0);
+            } else {
+                f32x4 b[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) b[t] = wt[cur][(c * 8 + t0 + t) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][e], b[t][e], acc[t], 0, 0, 0);
+            }
+        }
+        if (st + 1 < NSTAGE) { wt[cur ^ 1][tid] = wreg[0]; wt[cur ^ 1][512 + tid] = wreg[1]; }
+        __syncthreads();
+    }
+
+    // acc[t][reg]: cell row mt*16 + 4q + reg, hidden unit 16*(t0 + t) + r
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        if (t < nt_cnt) {
+            const int n = 16 * (t0 + t) + r;
+            const float bias = b1[n];
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) hs[mt * 16 + 4 * q + reg][n] = fmaxf(acc[t][reg] + bias, 0.f);
+        }
+    __syncthreads();
+    for (int it = tid; it < CELLS * 10; it += 512) {                  // fc2
+        const int cl = it / 10, j = it - 10 * cl;
+        float sacc = b2[j];
+        for (int n = 0; n < 128; n++) sacc = __builtin_fmaf(hs[cl][n], w2s[j][n], sacc);
+        lg[cl][j] = sacc;
+        if (cellbase + cl < B) logits[(cellbase + cl) * 10 + j] = sacc;
+    }
+    __syncthreads();
+    if (tid < CELLS && cellbase + tid < B && (digits || conf)) {
+        float best = lg[tid][0];
+        int arg = 0;
+        for (int j = 1; j < 10; j++)
+            if (lg[tid][j] > best) { best = lg[tid][j]; arg = j; }
+        if (digits) digits[cellbase + tid] = (u8)arg;
+        if (conf) {
+            float den = 0.f;
+            for (int j = 0; j < 10; j++) den += expf(lg[tid][j] - best);
+            conf[cellbase + tid] = 1.0f / den;
+        }
+    }
+}
+
 // preprocess_cell (pipeline/run.py:73-95) as a stand-alone call: one wave per cell, u8 in -> u8 {0,255} out
 __global__ __launch_bounds__(256) void k_preprocess_cells(const u8 *__restrict__ cells, long B, GaussTaps taps, u8 *__restrict__ out)
 {
@@ -597,6 +710,10 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
     }
     SV_LAUNCH_CHECK("k_conv_features");
     sv_time_scope ts(ctx, SVK_FC_HEAD, s);
+    static const int fc_algo = getenv("SV_FC_ALGO") ? atoi(getenv("SV_FC_ALGO")) : 1;   // tuning aid
+    if (fc_algo == 1 && B >= 81 * 64)        // enough frames to give most CUs a workgroup
+        hipLaunchKernelGGL(k_fc_head_frame, dim3((unsigned)((B + 80) / 81)), dim3(512), 0, s, ctx->features, B, w.fc1_wreg, w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
+    else
     hipLaunchKernelGGL(k_fc_head, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, ctx->features, B, w.fc1_wreg, w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
     SV_LAUNCH_CHECK("k_fc_head");
     return SV_OK;

@@ -414,3 +414,13 @@ def test_conv_algorithms_agree(golden_dir):
         outs.append(np.load(path))
     assert np.abs(outs[0] - outs[1]).max() <= 2e-5
     assert (outs[0].argmax(1) == outs[1].argmax(1)).all()
+
+
+def test_cnn_large_batch_frame_kernel(ctx, golden_dir):
+    """B >= 5184 cells switches fc1 to the one-workgroup-per-frame kernel (LDS-staged weights); ragged tail included."""
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    B = 81 * 64 + 37
+    cells = np.random.RandomState(37).randint(0, 256, (B, 28, 28)).astype(np.uint8)
+    cells[::3] = np.clip(cells[::3].astype(int) // 4 + 150, 0, 255).astype(np.uint8)
+    _check_cnn(ctx, sd, cells)

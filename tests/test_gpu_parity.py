@@ -424,3 +424,40 @@ def test_cnn_large_batch_frame_kernel(ctx, golden_dir):
     cells = np.random.RandomState(37).randint(0, 256, (B, 28, 28)).astype(np.uint8)
     cells[::3] = np.clip(cells[::3].astype(int) // 4 + 150, 0, 255).astype(np.uint8)
     _check_cnn(ctx, sd, cells)
+
+
+@pytest.mark.parametrize("H,W", [(3648, 2736), (123, 1000), (64, 244)])
+def test_preprocess_other_resolutions(ctx, H, W):
+    """The reference's test photos are 2736x3648 portrait; plus widths whose last 240-column strip is partial."""
+    rs = np.random.RandomState(H + W)
+    base = rs.randint(0, 256, (H // 8 + 2, W // 8 + 2, 3)).astype(np.uint8)
+    img = np.repeat(np.repeat(base, 8, 0), 8, 1)[:H, :W].copy()          # blocky structure + noise: edges everywhere
+    img = np.clip(img.astype(np.int16) + rs.randint(-12, 13, img.shape), 0, 255).astype(np.uint8)
+    got = ctx.preprocess(torch.from_numpy(img[None]).cuda()).cpu().numpy()[0]
+    assert (got == o.preprocess_for_grid_detection(img)).all()
+
+
+def test_real_photo_end_to_end(ctx, golden_dir):
+    """data/test_images/sample_4.jpg (the photo the reference's tests/test_integration.py:121 uses; committed as a data
+    fixture, decoded with PIL on both sides): K1 at 2736x3648, host corner search, K2, run.py glue, CNN with the trained
+    weights -- binary and cells bit-exact, digit indices equal to the oracle's."""
+    from PIL import Image
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.pipeline import recognize_image
+    img = np.asarray(Image.open(os.path.join(golden_dir, "sample_4.jpg")).convert("RGB"))[..., ::-1].copy()
+    assert img.shape == (3648, 2736, 3)
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    ctx.load_state_dict(sd)
+    d = torch.from_numpy(img).cuda()[None]
+    binary = ctx.preprocess(d)[0].cpu().numpy()
+    assert (binary == o.preprocess_for_grid_detection(img)).all()
+    corners = sva.host.find_grid_corners(binary)
+    assert corners is not None and (corners == o.find_grid_contour(binary)).all()
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners[None].astype(np.float32)))
+    cells = ctx.warp_cells(d, minv)[0].cpu().numpy()
+    assert (cells == o.warp_cells(img, corners.astype(np.float32))).all()
+    res = recognize_image(img, ctx=ctx)                                   # run.py order incl. preprocess_cell
+    el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(o.preprocess_cells(cells))[:, None])
+    assert (res["digits"] == ed.numpy()).all()
+    assert np.abs(res["logits"] - el.numpy()).max() <= LOGIT_TOL

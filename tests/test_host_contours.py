@@ -137,3 +137,22 @@ def test_buffer_protocol_and_bad_args(host):
     assert lib.sv_find_grid_corners_u8(None, 16, 16, 16, 0.1, 0.02, None) == -1
     with pytest.raises(TypeError):
         host.find_grid_corners(np.zeros((4, 4), np.float32))
+
+
+def test_reference_photos_success_rate(host):
+    """The reference prints 'CV success rate on test images: 4/5' (tests/test_integration.py:261).  The restated pipeline
+    (oracle K1 + host corner search) finds a grid on exactly 4 of the 5 photos.  Needs the reference tree (skipped elsewhere)."""
+    import os
+    from PIL import Image
+    d = "/root/reference/data/test_images"
+    if not os.path.isdir(d):
+        pytest.skip("reference tree not present")
+    found = []
+    for i in range(1, 6):
+        img = np.asarray(Image.open(os.path.join(d, f"sample_{i}.jpg")).convert("RGB"))[..., ::-1].copy()
+        b = o.preprocess_for_grid_detection(img)
+        g = host.find_grid_corners(b)
+        go = o.find_grid_contour(b)
+        assert (g is None) == (go is None) and (g is None or (g == go).all())
+        found.append(g is not None)
+    assert sum(found) == 4

@@ -496,7 +496,7 @@ int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pi
         dim3 grid((W + FW - 1) / FW, (H + FH - 1) / FH, n);
         if (aligned4) {
             const int nstrips = (W + MARCH_STRIP - 1) / MARCH_STRIP;
-            int nbands = (10240 + n * nstrips - 1) / (n * nstrips);      // ~2 rounds of 5 waves per SIMD on 256 CUs
+            int nbands = (12288 + n * nstrips - 1) / (n * nstrips);      // ~3 rounds of 4 waves per SIMD on 256 CUs (flat between 8k and 16k waves)
             if (nbands > H / 32) nbands = H / 32;
             if (nbands < 1) nbands = 1;
             const int TH = (H + nbands - 1) / nbands;

@@ -214,6 +214,12 @@ int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*784*/, lo
                             float *logits /*dev*/, uint8_t *digits /*dev or NULL*/,
                             float *conf /*dev or NULL*/, void *stream);
 
+/* F.softmax(output, dim=1) then probs.topk(top_k), pipeline/run_v2.py:165-178 (predict_cells_with_alternatives):
+ * per cell the k most probable classes, most probable first (index[.,0] = the predicted digit, prob[.,0] = its
+ * confidence, the rest = run_v2's `alternatives`).  Equal probabilities: lower class index first.  1 <= k <= 10. */
+int sv_softmax_topk_f32(sv_ctx *ctx, const float *logits /*dev, B*10*/, long B, int k,
+                        uint8_t *index /*dev, B*k*/, float *prob /*dev, B*k*/, void *stream);
+
 /* ---- the whole device-resident path ----------------------------------------------------------- */
 
 /* frames + homographies -> 81 digits per frame: K2 then K3 on `stream`, no host sync.

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sv_resize_linear_u8": [_p, _p, _i, _i, _pd, _p, _i, _i, _p],
     "sv_cell_ink_ratio_u8": [_p, _p, _l, _i, _p, _p, _p],
     "sv_preprocess_cells_u8": [_p, _p, _l, _p, _p],
+    "sv_softmax_topk_f32": [_p, _p, _l, _i, _p, _p, _p],
     "sv_cnn_forward_f32": [_p, _p, _l, _p, _p, _p, _p],
     "sv_cnn_forward_cells_u8": [_p, _p, _l, _i, _p, _p, _p, _p],
     "sv_frames_to_digits": [_p, _p, _i, _i, _i, _pd, _pd, _p, _i, _p, _p, _p, _p, _p],

@@ -681,6 +681,38 @@ int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s)
     return SV_OK;
 }
 
+// F.softmax + topk (pipeline/run_v2.py:165-178): one thread per cell, 10 logits in registers, k selection passes
+__global__ __launch_bounds__(256) void k_softmax_topk(const float *__restrict__ logits, long B, int k, u8 *__restrict__ index, float *__restrict__ prob)
+{
+    const long cell = (long)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= B) return;
+    float p[10];
+    float best = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { p[j] = logits[cell * 10 + j]; best = fmaxf(best, p[j]); }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 10; j++) { p[j] = expf(p[j] - best); den += p[j]; }
+    unsigned taken = 0;
+    for (int r = 0; r < k; r++) {
+        float top = -1.f;
+        int arg = 0;
+#pragma unroll
+        for (int j = 0; j < 10; j++)
+            if (!(taken >> j & 1) && p[j] > top) { top = p[j]; arg = j; }
+        taken |= 1u << arg;
+        index[cell * k + r] = (u8)arg;
+        prob[cell * k + r] = top / den;
+    }
+}
+
+int svk_softmax_topk(const float *logits, long B, int k, u8 *index, float *prob, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_softmax_topk, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, logits, B, k, index, prob);
+    SV_LAUNCH_CHECK("k_softmax_topk");
+    return SV_OK;
+}
+
 int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
 {
     const sv_weights &w = ctx->w;

@@ -477,6 +477,13 @@ extern "C" int sv_preprocess_cells_u8(sv_ctx *ctx, const uint8_t *cells, long B,
     return svk_preprocess_cells(cells, B, out, S(stream));
 }
 
+extern "C" int sv_softmax_topk_f32(sv_ctx *ctx, const float *logits, long B, int k, uint8_t *index, float *prob, void *stream)
+{
+    REQUIRE(ctx && logits && index && prob, "NULL argument");
+    REQUIRE(B > 0 && k >= 1 && k <= SV_CLASSES, "need B > 0 and 1 <= k <= 10");
+    return svk_softmax_topk(logits, B, k, index, prob, S(stream));
+}
+
 extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, int glue, uint8_t *cells, float *logits, uint8_t *digits, float *conf, void *stream)
 {
     REQUIRE(ctx && frames && minv && logits && digits, "NULL argument");

@@ -112,9 +112,10 @@ class FramePipeline:
         return out
 
 
-def recognize_image(image, model_state_dict=None, ctx=None, glue=Context.GLUE_RUNPY):
+def recognize_image(image, model_state_dict=None, ctx=None, glue=Context.GLUE_RUNPY, top_k=0):
     """One BGR image (numpy uint8 [H,W,3]) -> dict(grid 9x9 list, digits, confidences, corners) or None when no
-    grid is found -- the call order of pipeline/run.py:261-312, preprocess_cell (:73-95) included by default."""
+    grid is found -- the call order of pipeline/run.py:261-312, preprocess_cell (:73-95) included by default.
+    top_k > 1 adds run_v2's per-cell `alternatives` (pipeline/run_v2.py:165-178): 81 lists of (digit, prob), best excluded."""
     from .runtime import default_context
     ctx = ctx or default_context()
     if model_state_dict is not None:
@@ -127,8 +128,13 @@ def recognize_image(image, model_state_dict=None, ctx=None, glue=Context.GLUE_RU
     minv = ctx.minv_to_device(Context.corners_to_minv(corners[None].astype(np.float32)))
     out = ctx.frames_to_digits(frames, minv, glue=glue)
     digits = out["digits"][0].cpu().numpy()
-    return {"grid": [[int(digits[r * 9 + c]) for c in range(9)] for r in range(9)], "digits": digits,
-            "confidence": out["conf"][0].cpu().numpy(), "logits": out["logits"][0].cpu().numpy(), "corners": corners}
+    res = {"grid": [[int(digits[r * 9 + c]) for c in range(9)] for r in range(9)], "digits": digits,
+           "confidence": out["conf"][0].cpu().numpy(), "logits": out["logits"][0].cpu().numpy(), "corners": corners}
+    if top_k > 1:
+        idx, prob = ctx.softmax_topk(out["logits"][0], top_k)
+        idx, prob = idx.cpu().numpy(), prob.cpu().numpy()
+        res["alternatives"] = [[(int(idx[i, j]), float(prob[i, j])) for j in range(1, top_k)] for i in range(81)]
+    return res
 
 
 def run_solver(grid):

@@ -178,6 +178,15 @@ class Context:
                       "sv_cell_ink_ratio_u8")
         return ratio, otsu
 
+    def softmax_topk(self, logits, k=3):
+        """F.softmax(logits, 1).topk(k) (pipeline/run_v2.py:165-178): (index u8 [B,k], prob f32 [B,k]), best first."""
+        logits = logits.reshape(-1, 10).contiguous()
+        B = logits.shape[0]
+        index = torch.empty((B, k), dtype=torch.uint8, device=self.device)
+        prob = torch.empty((B, k), dtype=torch.float32, device=self.device)
+        _native.check(_native.lib().sv_softmax_topk_f32(self._h, _ptr(logits), B, int(k), _ptr(index), _ptr(prob), _stream_ptr()), "sv_softmax_topk_f32")
+        return index, prob
+
     def preprocess_cells(self, cells):
         """run.py's preprocess_cell on u8 cells [B,28,28] -> u8 {0,255} [B,28,28]."""
         out = torch.empty_like(cells)

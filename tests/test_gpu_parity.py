@@ -457,7 +457,30 @@ def test_real_photo_end_to_end(ctx, golden_dir):
     minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners[None].astype(np.float32)))
     cells = ctx.warp_cells(d, minv)[0].cpu().numpy()
     assert (cells == o.warp_cells(img, corners.astype(np.float32))).all()
-    res = recognize_image(img, ctx=ctx)                                   # run.py order incl. preprocess_cell
+    res = recognize_image(img, ctx=ctx, top_k=3)                          # run.py order incl. preprocess_cell
     el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(o.preprocess_cells(cells))[:, None])
     assert (res["digits"] == ed.numpy()).all()
     assert np.abs(res["logits"] - el.numpy()).max() <= LOGIT_TOL
+    tp, ti = torch.softmax(el, 1).topk(3)                                 # run_v2's alternatives (run_v2.py:165-178)
+    for i in range(81):
+        assert [a for a, _ in res["alternatives"][i]] == ti[i, 1:].tolist()
+        assert np.allclose([p for _, p in res["alternatives"][i]], tp[i, 1:].numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("k", [1, 3, 10])
+def test_softmax_topk_matches_torch(ctx, k):
+    """run_v2's epilogue (pipeline/run_v2.py:165-178): F.softmax + topk; indices exact, probabilities <= 1e-6 (f32).
+    Checker = torch on the CPU, the library the reference itself calls."""
+    rs = np.random.RandomState(k)
+    logits = (rs.randn(81 * 7 + 5, 10) * 6).astype(np.float32)
+    logits[3] = np.arange(10, dtype=np.float32)                       # ordered
+    logits[4] = -np.arange(10, dtype=np.float32) * 9                  # near-saturated softmax, still no exact ties
+    idx, prob = ctx.softmax_topk(torch.from_numpy(logits).cuda(), k)
+    want_p, want_i = torch.softmax(torch.from_numpy(logits), 1).topk(k)
+    assert (idx.cpu().numpy() == want_i.numpy()).all()
+    assert np.abs(prob.cpu().numpy() - want_p.numpy()).max() <= 1e-6
+
+
+def test_softmax_topk_bad_k(ctx):
+    with pytest.raises(RuntimeError):
+        ctx.softmax_topk(torch.zeros((4, 10), device="cuda"), 11)

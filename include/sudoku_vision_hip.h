@@ -220,6 +220,35 @@ int sv_cnn_forward_cells_u8(sv_ctx *ctx, const uint8_t *cells /*dev, B*784*/, lo
 int sv_softmax_topk_f32(sv_ctx *ctx, const float *logits /*dev, B*10*/, long B, int k,
                         uint8_t *index /*dev, B*k*/, float *prob /*dev, B*k*/, void *stream);
 
+/* ---- N4: JPEG front end -- what cv2.imread does before the path starts (pipeline/run.py:250, pipeline/run_v2.py:267,
+ * tests/test_integration.py:126).  Baseline / extended-sequential Huffman JPEG, 8-bit, gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0,
+ * restart intervals, EXIF orientation applied as imread applies it.  The serial Huffman bit stream is decoded on the host
+ * (threads: restart intervals of one image, or images of a batch); dequantisation, the inverse DCT (libjpeg's JDCT_ISLOW),
+ * "fancy" chroma up-sampling, YCbCr -> BGR and the orientation run on the GPU, so the frame is born in HBM where K1 and K2
+ * read it.  Progressive, arithmetic-coded, 12-bit, CMYK files: SV_ERR_UNSUPPORTED. */
+typedef struct sv_jpeg_info {
+    int width, height;              /* as stored */
+    int out_width, out_height;      /* after the EXIF orientation: the shape imread returns */
+    int components;                 /* 1 (gray) or 3 (YCbCr) */
+    int h_samp, v_samp;             /* luma sampling factors: 1x1, 2x1 or 2x2 */
+    int orientation;                /* EXIF tag 0x0112, 1..8 (1 when absent) */
+    int restart_interval;           /* MCUs, 0 = none */
+    long coef_count;                /* int16 values sv_jpeg_entropy_decode writes */
+} sv_jpeg_info;
+
+int sv_jpeg_parse(const uint8_t *data /*host*/, size_t size, sv_jpeg_info *info);
+
+/* Huffman decoding -> coefficient blocks: per component, blocks row-major over the MCU-padded block grid, 64 values per
+ * block in natural (row-major, de-zigzagged) order; quant: 3 x 64 quantiser steps, natural order, per component. */
+int sv_jpeg_entropy_decode(const uint8_t *data /*host*/, size_t size, int16_t *coef /*host, coef_count*/,
+                           uint16_t *quant /*host, 192*/, int threads);
+int sv_jpeg_entropy_decode_batch(const uint8_t *const *datas, const size_t *sizes, int n, int16_t *const *coefs /*host*/,
+                                 uint16_t *quants /*host, n*192*/, int threads, int *status /*n*/);
+
+/* Device half: coefficients -> BGR frame (out_height x out_width x 3, row pitch `pitch` bytes), asynchronous on `stream`. */
+int sv_jpeg_reconstruct_bgr_u8(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef /*dev*/,
+                               const uint16_t *quant /*dev, 192*/, uint8_t *bgr /*dev*/, ptrdiff_t pitch, void *stream);
+
 /* ---- the whole device-resident path ----------------------------------------------------------- */
 
 /* frames + homographies -> 81 digits per frame: K2 then K3 on `stream`, no host sync.

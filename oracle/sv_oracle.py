@@ -16,8 +16,8 @@ _SO = os.path.join(_HERE, "libsv_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile sv_oracle.c with gcc (make -C oracle) if the .so is missing or stale."""
-    src = os.path.join(_HERE, "sv_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("sv_oracle.c", "sv_jpeg_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
                        stdout=subprocess.DEVNULL)
     return _SO
@@ -260,3 +260,39 @@ def cell_ink_ratio(cell):
 
 def is_cell_empty(cell, threshold=0.02):
     return cell_ink_ratio(cell)[0] < threshold
+
+
+# ---- N4: cv2.imread on a baseline JPEG (oracle/sv_jpeg_oracle.c) ----
+class JpegInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "out_width", "out_height", "components", "h_samp", "v_samp",
+                                        "orientation", "restart_interval")] + [("coef_count", C.c_long)]
+
+
+def jpeg_info(data: bytes):
+    info = JpegInfo()
+    rc = lib().svo_jpeg_info_parse(data, C.c_size_t(len(data)), C.byref(info))
+    if rc:
+        raise ValueError(f"oracle: jpeg header rc={rc}")
+    return info
+
+
+def jpeg_coefficients(data: bytes):
+    """-> (coef int16 [coef_count] in the product's layout: per component, padded block grid row-major, 64 natural-order
+    values per block; quant uint16 [components, 64] natural order)."""
+    info = jpeg_info(data)
+    coef = np.empty(info.coef_count, np.int16)
+    quant = np.zeros((info.components, 64), np.uint16)
+    rc = lib().svo_jpeg_coefficients(data, C.c_size_t(len(data)), coef.ctypes.data_as(C.c_void_p), quant.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError(f"oracle: jpeg entropy decode rc={rc}")
+    return coef, quant
+
+
+def imdecode(data: bytes):
+    """cv2.imread / cv2.imdecode(IMREAD_COLOR) of a baseline JPEG -> BGR uint8 [H,W,3] (EXIF orientation applied)."""
+    info = jpeg_info(data)
+    out = np.empty((info.out_height, info.out_width, 3), np.uint8)
+    rc = lib().svo_jpeg_decode_bgr(data, C.c_size_t(len(data)), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError(f"oracle: jpeg decode rc={rc}")
+    return out

@@ -60,6 +60,7 @@ extern "C" int sv_ctx_destroy(sv_ctx *ctx)
     if (ctx->features) (void)hipFree(ctx->features);
     if (ctx->cells) (void)hipFree(ctx->cells);
     if (ctx->cells2) (void)hipFree(ctx->cells2);
+    if (ctx->jpeg_planes) (void)hipFree(ctx->jpeg_planes);
     for (auto &t : ctx->timeline) { (void)hipEventDestroy(t.t0); (void)hipEventDestroy(t.t1); }
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -482,6 +483,20 @@ extern "C" int sv_softmax_topk_f32(sv_ctx *ctx, const float *logits, long B, int
     REQUIRE(ctx && logits && index && prob, "NULL argument");
     REQUIRE(B > 0 && k >= 1 && k <= SV_CLASSES, "need B > 0 and 1 <= k <= 10");
     return svk_softmax_topk(logits, B, k, index, prob, S(stream));
+}
+
+extern "C" int sv_jpeg_reconstruct_bgr_u8(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint16_t *quant, uint8_t *bgr, ptrdiff_t pitch, void *stream)
+{
+    REQUIRE(ctx && info && coef && quant && bgr, "NULL argument");
+    REQUIRE(info->width > 0 && info->height > 0 && info->width < 65536 && info->height < 65536, "bad image size");
+    REQUIRE(info->components == 1 || info->components == 3, "components must be 1 or 3");
+    REQUIRE((info->h_samp == 1 && info->v_samp == 1) || (info->h_samp == 2 && (info->v_samp == 1 || info->v_samp == 2)), "sampling must be 1x1, 2x1 or 2x2");
+    REQUIRE(info->orientation >= 1 && info->orientation <= 8, "orientation must be 1..8");
+    const bool swap = info->orientation >= 5;
+    REQUIRE(info->out_width == (swap ? info->height : info->width) && info->out_height == (swap ? info->width : info->height), "out_width/out_height do not match the orientation");
+    REQUIRE(pitch >= 3 * (ptrdiff_t)info->out_width, "pitch smaller than a row");
+    REQUIRE(((uintptr_t)coef & 15) == 0 && ((uintptr_t)quant & 15) == 0, "coef and quant must be 16-byte aligned");
+    return svk_jpeg_reconstruct(ctx, info, coef, quant, bgr, pitch, S(stream));
 }
 
 extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, int glue, uint8_t *cells, float *logits, uint8_t *digits, float *conf, void *stream)

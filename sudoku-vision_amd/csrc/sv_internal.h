@@ -35,6 +35,8 @@ struct sv_ctx {
     u8 *cells = nullptr;        // [cells][784]
     u8 *cells2 = nullptr;       // [cells][784] preprocess_cell output (SV_GLUE_RUNPY)
     long cap_cells = 0;
+    u8 *jpeg_planes = nullptr;  // decoded component planes (MCU-padded) between the IDCT and the colour kernel
+    size_t cap_jpeg = 0;
     int precision = 0;          // SV_PREC_F32 / SV_PREC_BF16 (sv_ctx_set_precision)
     // optional per-kernel timing (sv_timing_begin/sv_timing_end): hipEvents on the launch stream
     bool timing = false;
@@ -88,6 +90,7 @@ int svk_resize_linear(const u8 *src, int sh, int sw, ptrdiff_t pitch, u8 *dst, i
 int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8 *digits, float *conf, hipStream_t s);
 int svk_cell_ink_ratio(const u8 *cells, long B, int npx, float *ratio, int *otsu, hipStream_t s);
 int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s);
+int svk_jpeg_reconstruct(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint16_t *quant, u8 *bgr, ptrdiff_t pitch, hipStream_t s);
 int svk_softmax_topk(const float *logits, long B, int k, u8 *index, float *prob, hipStream_t s);
 
 // host helpers

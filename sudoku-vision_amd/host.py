@@ -114,3 +114,25 @@ def solve_sudoku(grid):
     res = C.c_int()
     _native.check(_native.lib().sv_solve_sudoku(g.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(res)), "sv_solve_sudoku")
     return res.value, out.reshape(9, 9)
+
+
+# ---- JPEG front end, host half (csrc/host_jpeg.cpp): header parsing and Huffman decoding -------------------
+def jpeg_parse(data: bytes):
+    """-> _native.JpegInfo (sv_jpeg_info).  Raises NativeError for non-JPEG data and for unsupported JPEG flavours."""
+    info = _native.JpegInfo()
+    _native.check(_native.lib().sv_jpeg_parse(data, len(data), C.byref(info)), "sv_jpeg_parse")
+    return info
+
+
+def jpeg_entropy_decode(data: bytes, coef=None, quant=None, threads=1):
+    """-> (info, coef int16 [coef_count], quant uint16 [3,64]).  coef/quant may be caller-owned (e.g. pinned) numpy arrays."""
+    info = jpeg_parse(data)
+    if coef is None:
+        coef = np.empty(info.coef_count, np.int16)
+    if quant is None:
+        quant = np.empty((3, 64), np.uint16)
+    if coef.dtype != np.int16 or coef.size < info.coef_count or not coef.flags.c_contiguous:
+        raise ValueError("coef must be a contiguous int16 array of at least info.coef_count values")
+    _native.check(_native.lib().sv_jpeg_entropy_decode(data, len(data), coef.ctypes.data_as(C.c_void_p), quant.ctypes.data_as(C.c_void_p), int(threads)),
+                  "sv_jpeg_entropy_decode")
+    return info, coef, quant

@@ -113,14 +113,17 @@ class FramePipeline:
 
 
 def recognize_image(image, model_state_dict=None, ctx=None, glue=Context.GLUE_RUNPY, top_k=0):
-    """One BGR image (numpy uint8 [H,W,3]) -> dict(grid 9x9 list, digits, confidences, corners) or None when no
+    """One BGR image (numpy uint8 [H,W,3], or a CUDA uint8 tensor of that shape) -> dict(grid 9x9 list, digits, confidences, corners) or None when no
     grid is found -- the call order of pipeline/run.py:261-312, preprocess_cell (:73-95) included by default.
     top_k > 1 adds run_v2's per-cell `alternatives` (pipeline/run_v2.py:165-178): 81 lists of (digit, prob), best excluded."""
     from .runtime import default_context
     ctx = ctx or default_context()
     if model_state_dict is not None:
         ctx.load_state_dict(model_state_dict)
-    frames = torch.from_numpy(np.ascontiguousarray(image)).to(ctx.device)[None]
+    if isinstance(image, torch.Tensor):             # already in HBM (imgcodecs.imread(..., device=True))
+        frames = image.contiguous()[None]
+    else:
+        frames = torch.from_numpy(np.ascontiguousarray(image)).to(ctx.device)[None]
     binary = ctx.preprocess(frames)[0].cpu().numpy()
     corners = host.find_grid_corners(binary)
     if corners is None:

@@ -178,6 +178,27 @@ class Context:
                       "sv_cell_ink_ratio_u8")
         return ratio, otsu
 
+    def imdecode(self, data: bytes, threads=1, out=None):
+        """cv2.imdecode / cv2.imread of a baseline JPEG -> BGR uint8 CUDA tensor [H,W,3] (EXIF orientation applied).
+        Huffman decoding on the host (csrc/host_jpeg.cpp) into a pinned staging buffer, everything after it on the GPU."""
+        from . import host
+        info = host.jpeg_parse(data)
+        n = int(info.coef_count)
+        if getattr(self, "_jpeg_pin", None) is None or self._jpeg_pin.numel() < n + 192 + 8:
+            self._jpeg_pin = torch.empty(n + 192 + 8, dtype=torch.int16).pin_memory()
+            self._jpeg_dev = torch.empty(n + 192 + 8, dtype=torch.int16, device=self.device)
+        else:
+            torch.cuda.current_stream(self.device).synchronize()      # the previous decode may still be reading the staging buffer
+        qoff = (n + 7) // 8 * 8                                         # keeps the quantiser block 16-byte aligned
+        pin = self._jpeg_pin.numpy()
+        host.jpeg_entropy_decode(data, coef=pin[:n], quant=pin[qoff:qoff + 192].view(np.uint16).reshape(3, 64), threads=threads)
+        self._jpeg_dev[:qoff + 192].copy_(self._jpeg_pin[:qoff + 192], non_blocking=True)
+        if out is None:
+            out = torch.empty((info.out_height, info.out_width, 3), dtype=torch.uint8, device=self.device)
+        _native.check(_native.lib().sv_jpeg_reconstruct_bgr_u8(self._h, C.byref(info), _ptr(self._jpeg_dev), C.c_void_p(self._jpeg_dev.data_ptr() + 2 * qoff),
+                                                               _ptr(out), out.stride(0), _stream_ptr()), "sv_jpeg_reconstruct_bgr_u8")
+        return out
+
     def softmax_topk(self, logits, k=3):
         """F.softmax(logits, 1).topk(k) (pipeline/run_v2.py:165-178): (index u8 [B,k], prob f32 [B,k]), best first."""
         logits = logits.reshape(-1, 10).contiguous()

@@ -1,0 +1,177 @@
+"""Scope row N4 (JPEG decode for real-image feeds; replaces cv2.imread, pipeline/run.py:250).
+
+CPU part: the oracle (oracle/sv_jpeg_oracle.c) is pinned bit-for-bit against Pillow's libjpeg-turbo decoder (the same
+library family and defaults cv2.imread decodes with; cv2 itself is absent from this image), and the product's host-side
+entropy decoder (csrc/host_jpeg.cpp, runs without a GPU) is checked against the oracle's coefficients.
+"""
+import glob
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image, ImageOps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import sv_oracle as o  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF_PHOTOS = sorted(glob.glob("/root/reference/data/test_images/sample_*.jpg"))
+
+
+def synth_image(h, w, seed, gray=False):
+    """Smooth structure + edges + noise, so that every AC band and the chroma planes carry signal."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    chans = []
+    for c in range(1 if gray else 3):
+        base = 128 + 90 * np.sin(xx / (7.0 + 3 * c) + seed) * np.cos(yy / (5.0 + 2 * c))
+        base += 60 * (((xx // 9) + (yy // 7) + c) % 2) + rs.randint(-20, 21, (h, w))
+        chans.append(np.clip(base, 0, 255).astype(np.uint8))
+    return chans[0] if gray else np.stack(chans, -1)
+
+
+def encode(img, **kw):
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def pil_bgr(data):
+    """What the checker of record says: Pillow's decode, EXIF orientation applied as cv2.imread does, RGB -> BGR."""
+    im = ImageOps.exif_transpose(Image.open(io.BytesIO(data)))
+    return np.asarray(im.convert("RGB"))[..., ::-1]
+
+
+CASES = [  # (h, w, kwargs)
+    (64, 80, dict(quality=90, subsampling=0)),
+    (64, 80, dict(quality=90, subsampling=1)),
+    (64, 80, dict(quality=90, subsampling=2)),
+    (61, 83, dict(quality=75, subsampling=2)),            # odd sizes: partial MCUs, odd chroma edge
+    (50, 37, dict(quality=30, subsampling=1)),
+    (17, 16, dict(quality=95, subsampling=2)),
+    (8, 8, dict(quality=85, subsampling=2)),
+    (3, 4, dict(quality=85, subsampling=2)),              # chroma width 2: libjpeg falls back to replication
+    (5, 3, dict(quality=85, subsampling=1)),
+    (1, 1, dict(quality=85, subsampling=2)),
+    (9, 5, dict(quality=85, subsampling=2)),              # chroma width 3: smallest fancy case
+    (120, 200, dict(quality=100, subsampling=0)),         # quality 100: large coefficients, clamping
+    (120, 200, dict(quality=5, subsampling=2)),           # quality 5: 16-bit-ish quantisers, heavy ringing
+    (96, 144, dict(quality=80, subsampling=2, restart_marker_blocks=3)),
+    (96, 144, dict(quality=80, subsampling=0, restart_marker_rows=1)),
+    (70, 70, dict(quality=80, subsampling=2, optimize=True)),     # optimised (non-default) Huffman tables
+]
+
+
+@pytest.mark.parametrize("h,w,kw", CASES)
+def test_oracle_matches_pillow_synthetic(h, w, kw):
+    data = encode(synth_image(h, w, h * 131 + w), **kw)
+    assert (o.imdecode(data) == pil_bgr(data)).all()
+
+
+def test_oracle_matches_pillow_gray():
+    for h, w in ((40, 56), (33, 21)):
+        data = encode(synth_image(h, w, 5, gray=True), quality=88)
+        assert o.jpeg_info(data).components == 1
+        assert (o.imdecode(data) == pil_bgr(data)).all()
+
+
+@pytest.mark.parametrize("orient", range(1, 9))
+def test_oracle_exif_orientation(orient):
+    """The 8 EXIF orientations against PIL.ImageOps.exif_transpose (the standard mapping cv2.imread applies as well)."""
+    img = synth_image(40, 72, 11)
+    exif = Image.Exif()
+    exif[0x0112] = orient
+    data = encode(img, quality=90, subsampling=2, exif=exif)
+    info = o.jpeg_info(data)
+    assert info.orientation == orient and (info.out_height, info.out_width) == ((72, 40) if orient >= 5 else (40, 72))
+    assert (o.imdecode(data) == pil_bgr(data)).all()
+
+
+def test_oracle_matches_pillow_fixture_photo():
+    """tests/golden/sample_4.jpg = the reference's data/test_images/sample_4.jpg (data fixture), 2736x3648 4:2:0."""
+    data = open(os.path.join(GOLDEN, "sample_4.jpg"), "rb").read()
+    info = o.jpeg_info(data)
+    assert (info.width, info.height, info.components, info.h_samp, info.v_samp) == (2736, 3648, 3, 2, 2)
+    assert (o.imdecode(data) == pil_bgr(data)).all()
+
+
+@pytest.mark.skipif(not REF_PHOTOS, reason="reference tree not present (GPU box)")
+def test_oracle_matches_pillow_all_reference_photos():
+    for f in REF_PHOTOS:
+        data = open(f, "rb").read()
+        assert (o.imdecode(data) == pil_bgr(data)).all(), f
+
+
+def test_oracle_rejects_what_it_does_not_restate():
+    prog = encode(synth_image(32, 32, 1), quality=80, progressive=True)
+    with pytest.raises(ValueError):
+        o.imdecode(prog)
+    with pytest.raises(ValueError):
+        o.imdecode(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
+    cmyk = io.BytesIO()
+    Image.fromarray(synth_image(16, 16, 2)).convert("CMYK").save(cmyk, "JPEG")
+    with pytest.raises(ValueError):
+        o.imdecode(cmyk.getvalue())
+
+
+# ---- product, host half (no GPU needed): csrc/host_jpeg.cpp vs the oracle ------------------------------------------
+@pytest.fixture(scope="module")
+def host():
+    import __graft_entry__ as g
+    import sudoku_vision_amd as sva
+    if not os.path.exists(sva._native.LIB_PATH):
+        g.build()
+    return sva.host
+
+
+def _same_info(a, b):
+    return all(getattr(a, f) == getattr(b, f) for f, _ in type(a)._fields_)
+
+
+@pytest.mark.parametrize("h,w,kw", CASES)
+def test_host_entropy_decode_matches_oracle(host, h, w, kw):
+    data = encode(synth_image(h, w, h * 131 + w), **kw)
+    info, coef, quant = host.jpeg_entropy_decode(data, threads=3)          # threads only matter with restart intervals
+    assert _same_info(info, o.jpeg_info(data))
+    oc, oq = o.jpeg_coefficients(data)
+    assert (coef == oc).all() and (quant == oq).all()
+
+
+def test_host_entropy_decode_gray_orientation_photo(host):
+    exif = Image.Exif()
+    exif[0x0112] = 6
+    for data in (encode(synth_image(40, 56, 5, gray=True), quality=88),
+                 encode(synth_image(40, 72, 11), quality=90, exif=exif),
+                 open(os.path.join(GOLDEN, "sample_4.jpg"), "rb").read()):
+        info, coef, quant = host.jpeg_entropy_decode(data)
+        assert _same_info(info, o.jpeg_info(data))
+        oc, oq = o.jpeg_coefficients(data)
+        assert (coef == oc).all() and (quant[:info.components] == oq).all()
+
+
+def test_host_entropy_decode_restart_intervals_threaded(host):
+    """Restart intervals are independent bit streams: decoded on several threads, same coefficients."""
+    data = encode(synth_image(480, 640, 3), quality=85, subsampling=2, restart_marker_rows=1)
+    assert o.jpeg_info(data).restart_interval == 40
+    one = host.jpeg_entropy_decode(data, threads=1)[1]
+    many = host.jpeg_entropy_decode(data, threads=8)[1]
+    assert (one == many).all() and (one == o.jpeg_coefficients(data)[0]).all()
+
+
+def test_host_jpeg_errors(host):
+    import sudoku_vision_amd as sva
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_UNSUPPORTED"):
+        host.jpeg_parse(encode(synth_image(32, 32, 1), quality=80, progressive=True))
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_BAD_ARG"):
+        host.jpeg_parse(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
+    good = encode(synth_image(64, 64, 1), quality=80)
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_BAD_ARG"):
+        host.jpeg_entropy_decode(good[:len(good) // 4])                    # cut inside the tables / before the scan
+    cmyk = io.BytesIO()
+    Image.fromarray(synth_image(16, 16, 2)).convert("CMYK").save(cmyk, "JPEG")
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_UNSUPPORTED"):
+        host.jpeg_parse(cmyk.getvalue())

@@ -28,6 +28,7 @@ struct HuffTable {
     int32_t maxcode[18];                // per length, left-aligned to 16 bits (exclusive upper bound); sentinel at [17]
     int32_t delta[17];                  // vals index = delta[len] + code
     uint8_t vals[256];
+    int32_t fast_ac[1 << kLook];        // AC tables: (value << 16) | (run << 8) | total bits when code + magnitude bits fit kLook, else 0
     bool defined = false;
 
     bool define(const uint8_t *counts /*16*/, const uint8_t *symbols, int total)
@@ -48,6 +49,17 @@ struct HuffTable {
             code <<= 1;
         }
         maxcode[17] = 0x7fffffff;
+        // short code + short magnitude in one probe: the bits after the code ARE the magnitude field
+        for (int i = 0; i < (1 << kLook); i++) {
+            fast_ac[i] = 0;
+            const int e = look[i];
+            if (!e) continue;
+            const int len = e >> 8, run = (e >> 4) & 15, size = e & 15;
+            if (size == 0 || len + size > kLook) continue;
+            int v = (i >> (kLook - len - size)) & ((1 << size) - 1);
+            if (v < (1 << (size - 1))) v += 1 - (1 << size);
+            fast_ac[i] = (int32_t)((unsigned)v << 16 | (unsigned)run << 8 | (unsigned)(len + size));
+        }
         defined = true;
         return true;
     }
@@ -228,8 +240,18 @@ struct BitStream {
 
     BitStream(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
 
-    inline void refill()
+    inline void refill()                // afterwards at least 32 bits are buffered (code <= 16 + magnitude <= 16)
     {
+        if (have > 32) return;
+        if (p + 4 <= end) {             // four bytes at once when none of them is 0xFF (the common case)
+            const uint32_t w = (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3];
+            if (((~w - 0x01010101u) & w & 0x80808080u) == 0) {
+                acc |= (uint64_t)w << (32 - have);
+                have += 32;
+                p += 4;
+                return;
+            }
+        }
         while (have <= 56) {
             unsigned c = 0;
             if (p < end) {
@@ -283,12 +305,21 @@ void decode_interval(const Header &h, const Scan &scan, const uint8_t *b, const 
             for (int v = 0; v < s.nv; v++)
                 for (int u = 0; u < s.nh; u++) {
                     int16_t *blk = coef + c.offset + ((long)(my * s.nv + v) * c.bw + (mx * s.nh + u)) * 64;
+                    memset(blk, 0, 64 * sizeof(int16_t));           // cleared while the lines are about to be written anyway
                     bs.refill();
                     const int t = bs.symbol(dct) & 15;
                     if (t) pred[i] += bs.take_signed(t);
                     blk[0] = (int16_t)pred[i];
                     for (int k = 1; k < 64;) {
                         bs.refill();
+                        const int32_t f = act.fast_ac[bs.peek16() >> (16 - kLook)];
+                        if (f) {
+                            k += (f >> 8) & 15;
+                            if (k > 63) break;
+                            bs.drop(f & 255);
+                            blk[kNatural[k++]] = (int16_t)(f >> 16);
+                            continue;
+                        }
                         const int rs = bs.symbol(act), run = rs >> 4, size = rs & 15;
                         if (size == 0) {
                             if (run != 15) break;                   // EOB
@@ -324,7 +355,7 @@ size_t split_intervals(const uint8_t *d, size_t size, size_t pos, std::vector<st
 
 int entropy_decode(const uint8_t *d, size_t size, Header &h, int16_t *coef, int threads)
 {
-    memset(coef, 0, (size_t)h.coef_count * sizeof(int16_t));
+    bool cleared = false;                                          // interleaved scans clear each block as they reach it
     size_t pos = h.first_scan;
     int covered = 0;
     while (covered < h.ncomp) {
@@ -348,6 +379,10 @@ int entropy_decode(const uint8_t *d, size_t size, Header &h, int16_t *coef, int 
         const uint8_t *tail = s + 1 + 2 * scan.ns;
         if (tail[0] != 0 || tail[1] != 63 || tail[2] != 0) return sv_fail(SV_ERR_UNSUPPORTED, "jpeg: spectral selection / successive approximation in a sequential file");
         if (scan.ns == 1) {                                        // non-interleaved: the component's own block grid
+            if (h.ncomp > 1 && !cleared) {                         // ... which does not reach the MCU padding blocks
+                memset(coef, 0, (size_t)h.coef_count * sizeof(int16_t));
+                cleared = true;
+            }
             const Component &c = h.comp[scan.sc[0].comp];
             scan.mcu_cols = ((h.width * c.h + h.hmax - 1) / h.hmax + 7) / 8;
             scan.mcu_rows = ((h.height * c.v + h.vmax - 1) / h.vmax + 7) / 8;

@@ -199,6 +199,45 @@ class Context:
                                                                _ptr(out), out.stride(0), _stream_ptr()), "sv_jpeg_reconstruct_bgr_u8")
         return out
 
+    def imdecode_batch(self, datas, threads=16):
+        """A batch of JPEG files -> uint8 CUDA tensor [n,H,W,3] when all share a shape, else a list of [H,W,3] tensors.
+        Images are Huffman-decoded on `threads` host threads (sv_jpeg_entropy_decode_batch) into one pinned buffer, cross
+        PCIe in one copy, and are reconstructed on the GPU back to back."""
+        from . import host
+        n = len(datas)
+        datas = [bytes(d) for d in datas]
+        infos = [host.jpeg_parse(d) for d in datas]
+        offs, total = [], 0
+        for info in infos:
+            offs.append(total)
+            total += (int(info.coef_count) + 7) // 8 * 8
+        qoff = total
+        total += 192 * n
+        if getattr(self, "_jpeg_pin", None) is None or self._jpeg_pin.numel() < total:
+            self._jpeg_pin = torch.empty(total, dtype=torch.int16).pin_memory()
+            self._jpeg_dev = torch.empty(total, dtype=torch.int16, device=self.device)
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+        base = self._jpeg_pin.data_ptr()
+        bufs = (C.c_char_p * n)(*datas)
+        sizes = (C.c_size_t * n)(*[len(d) for d in datas])
+        coefs = (C.c_void_p * n)(*[base + 2 * o for o in offs])
+        status = (C.c_int * n)()
+        _native.check(_native.lib().sv_jpeg_entropy_decode_batch(bufs, sizes, n, coefs, C.c_void_p(base + 2 * qoff), int(threads), status),
+                      "sv_jpeg_entropy_decode_batch")
+        self._jpeg_dev[:total].copy_(self._jpeg_pin[:total], non_blocking=True)
+        same = all((i.out_height, i.out_width) == (infos[0].out_height, infos[0].out_width) for i in infos)
+        if same:
+            out = torch.empty((n, infos[0].out_height, infos[0].out_width, 3), dtype=torch.uint8, device=self.device)
+            outs = [out[i] for i in range(n)]
+        else:
+            outs = [torch.empty((i.out_height, i.out_width, 3), dtype=torch.uint8, device=self.device) for i in infos]
+        dbase = self._jpeg_dev.data_ptr()
+        for i in range(n):
+            _native.check(_native.lib().sv_jpeg_reconstruct_bgr_u8(self._h, C.byref(infos[i]), C.c_void_p(dbase + 2 * offs[i]), C.c_void_p(dbase + 2 * (qoff + 192 * i)),
+                                                                   _ptr(outs[i]), outs[i].stride(0), _stream_ptr()), "sv_jpeg_reconstruct_bgr_u8")
+        return out if same else outs
+
     def softmax_topk(self, logits, k=3):
         """F.softmax(logits, 1).topk(k) (pipeline/run_v2.py:165-178): (index u8 [B,k], prob f32 [B,k]), best first."""
         logits = logits.reshape(-1, 10).contiguous()

@@ -37,26 +37,45 @@ struct Contour { size_t first, count; int x0, y0, x1, y1; };  // slice of `point
 
 class BorderScanner {
   public:
-    BorderScanner(const u8 *bin, int H, int W, ptrdiff_t pitch) : h_(H), w_(W), step_(W + 2), img_((size_t)(W + 2) * (H + 2), 0)
+    BorderScanner(const u8 *bin, int H, int W, ptrdiff_t pitch) : h_(H), w_(W), step_(W + 2), own_((size_t)(W + 2) * (H + 2), 0)
     {
+        base_ = own_.data();
         for (int y = 0; y < H; y++) {
             const u8 *s = bin + (ptrdiff_t)y * pitch;
-            int8_t *d = img_.data() + (size_t)(y + 1) * step_ + 1;
+            int8_t *d = base_ + (size_t)(y + 1) * step_ + 1;
             for (int x = 0; x < W; x++) d[x] = s[x] != 0;
         }
         for (int k = 0; k < 8; k++) delta_[k] = delta_[k + 8] = kDy[k] * step_ + kDx[k];
     }
 
-    // from a bit-packed image: 1 bit per pixel, LSB = leftmost, W/32 words per row (sv_despeckle_u8's packed output)
-    BorderScanner(const uint32_t *bits, int H, int W) : h_(H), w_(W), step_(W + 2), img_((size_t)(W + 2) * (H + 2), 0)
+    // from a bit-packed image: 1 bit per pixel, LSB = leftmost, W/32 words per row (sv_despeckle_u8's packed output).
+    // The label image lives in a per-thread buffer that is reused from frame to frame (a fresh 2 MB allocation costs more
+    // in page faults than the whole search); only the byte spans the previous frame wrote are cleared.
+    BorderScanner(const uint32_t *bits, int H, int W) : h_(H), w_(W), step_(W + 2), bits_(bits), wpr_(W >> 5)
     {
-        const int wpr = W >> 5;
+        ScanBuffer &tl = scan_buffer();
+        if (tl.h != H || tl.w != W) {
+            tl.img.assign((size_t)(W + 2) * (H + 2), 0);
+            tl.span.assign((size_t)H + 2, {0, 0});
+            tl.h = H; tl.w = W;
+        } else {
+            for (int y = 1; y <= H; y++) {
+                auto &sp = tl.span[y];
+                if (sp.second > sp.first) memset(tl.img.data() + (size_t)y * step_ + sp.first, 0, (size_t)(sp.second - sp.first));
+                sp = {0, 0};
+            }
+        }
+        base_ = tl.img.data();
+        span_ = tl.span.data();
         for (int y = 0; y < H; y++) {
-            const uint32_t *s = bits + (size_t)y * wpr;
-            int8_t *d = img_.data() + (size_t)(y + 1) * step_ + 1;
-            for (int k = 0; k < wpr; k++) {
+            const uint32_t *s = bits + (size_t)y * wpr_;
+            int8_t *d = base_ + (size_t)(y + 1) * step_ + 1;
+            int lo = -1, hi = -1;
+            for (int k = 0; k < wpr_; k++) {
                 uint32_t v = s[k];
                 if (!v) continue;                              // rows are mostly empty after despeckling
+                if (lo < 0) lo = k;
+                hi = k;
                 for (int b = 0; b < 4; b++, v >>= 8) {
                     // 8 bits -> 8 bytes of 0/1
                     uint64_t x = (uint64_t)(v & 0xFF) * 0x0101010101010101ull & 0x8040201008040201ull;
@@ -64,6 +83,7 @@ class BorderScanner {
                     memcpy(d + 32 * k + 8 * b, &x, 8);
                 }
             }
+            if (lo >= 0) span_[y + 1] = {1 + 32 * lo, 1 + 32 * (hi + 1)};
         }
         for (int k = 0; k < 8; k++) delta_[k] = delta_[k + 8] = kDy[k] * step_ + kDx[k];
     }
@@ -72,12 +92,14 @@ class BorderScanner {
     void run()
     {
         for (int y = 1; y <= h_; y++) {
-            int8_t *row = img_.data() + (size_t)y * step_;
+            if (bits_ && span_[y].second == 0) continue;       // nothing on this row
+            int8_t *row = base_ + (size_t)y * step_;
             int last_marked = 0;  // x of the last labelled pixel seen on this row (0 = padding column)
             int prev = 0;
             int x = 1;
             while (x <= w_) {
-                x = skip_run(row, x, prev);
+                // background is never labelled, so from a background pixel the next non-zero label is the next set bit
+                x = (bits_ && prev == 0) ? next_set(bits_ + (size_t)(y - 1) * wpr_, x) : skip_run(row, x, prev);
                 if (x > w_) break;
                 int p = row[x];
                 if (prev == 0 && p == 1 && row[last_marked] <= 0) {
@@ -96,6 +118,18 @@ class BorderScanner {
     std::vector<Contour> contours;  // in discovery order (cv2 reports them reversed)
 
   private:
+    // first x' >= x (1-based) whose pixel is set in the bit row, or w_+1
+    int next_set(const uint32_t *brow, int x) const
+    {
+        const int px = x - 1;
+        int k = px >> 5;
+        uint32_t v = brow[k] >> (px & 31);
+        if (v) return x + __builtin_ctz(v);
+        for (k++; k < wpr_; k++)
+            if (brow[k]) return 32 * k + __builtin_ctz(brow[k]) + 1;
+        return w_ + 1;
+    }
+
     // first x' >= x with row[x'] != prev (or w_+1)
     int skip_run(const int8_t *row, int x, int prev) const
     {
@@ -153,8 +187,15 @@ class BorderScanner {
         contours.push_back(c);
     }
 
+    struct ScanBuffer { std::vector<int8_t> img; std::vector<std::pair<int, int>> span; int h = 0, w = 0; };
+    static ScanBuffer &scan_buffer() { static thread_local ScanBuffer b; return b; }
+
     int h_, w_, step_;
-    std::vector<int8_t> img_;
+    std::vector<int8_t> own_;
+    int8_t *base_ = nullptr;
+    const uint32_t *bits_ = nullptr;
+    int wpr_ = 0;
+    std::pair<int, int> *span_ = nullptr;
     int delta_[16];
 };
 

@@ -484,3 +484,50 @@ def test_softmax_topk_matches_torch(ctx, k):
 def test_softmax_topk_bad_k(ctx):
     with pytest.raises(RuntimeError):
         ctx.softmax_topk(torch.zeros((4, 10), device="cuda"), 11)
+
+
+def test_full_size_batch_properties(ctx, golden_dir):
+    """BASELINE configs[1] at full size (256 synthetic 1080p frames, the bench's seed): size-independent properties of the
+    whole path, plus an oracle spot check on three frames of the batch.
+      * K1 output is binary and identical whether a frame is processed alone, in a ragged sub-batch or in the full batch;
+      * K2 cells likewise (bit-exact); digits equal, logits within 1e-5 across batch shapes (the fc kernel's summation order
+        depends on the batch size, the conv kernel's does not);
+      * round-robin shards (N = 2, 3) recombine to the unsharded result -- the multi-GPU partitioning loses nothing;
+      * frames 0, 101 and 255 against the oracle: binary and cells bit-exact, logits <= 1e-4, digits equal."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd import sharding
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    ctx.load_state_dict(sd)
+    n = 256
+    frames, corners, _ = _frames(n, 1080, 1920, seed=1234)
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners))
+    binary = ctx.preprocess(frames)
+    vals = torch.unique(binary)
+    assert set(vals.cpu().tolist()) <= {0, 255}
+    full = ctx.frames_to_digits(frames, minv, keep_cells=True)
+    full = {k: v.clone() for k, v in full.items()}
+    # ragged sub-batches and a lone frame
+    for lo, hi in ((0, 100), (100, 256), (17, 18)):
+        assert torch.equal(ctx.preprocess(frames[lo:hi]), binary[lo:hi])
+        part = ctx.frames_to_digits(frames[lo:hi], minv[lo:hi], keep_cells=True)
+        assert torch.equal(part["cells"], full["cells"][lo:hi])
+        assert torch.equal(part["digits"], full["digits"][lo:hi])
+        assert (part["logits"] - full["logits"][lo:hi]).abs().max().item() <= 1e-5
+    # round-robin shards recombine
+    for world in (2, 3):
+        digits = torch.empty_like(full["digits"])
+        for rank in range(world):
+            idx = torch.tensor(sharding.shard_indices(n, rank, world), device="cuda")
+            part = ctx.frames_to_digits(frames[idx].contiguous(), minv[idx].contiguous())
+            digits[idx] = part["digits"]
+        assert torch.equal(digits, full["digits"])
+    # oracle spot check
+    for i in (0, 101, 255):
+        host = frames[i].cpu().numpy()
+        assert (binary[i].cpu().numpy() == o.preprocess_for_grid_detection(host)).all()
+        cells = o.warp_cells(host, corners[i])
+        assert (full["cells"][i].cpu().numpy() == cells).all()
+        el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(cells)[:, None])
+        assert np.abs(full["logits"][i].cpu().numpy() - el.numpy()).max() <= LOGIT_TOL
+        assert (full["digits"][i].cpu().numpy() == ed.numpy()).all()

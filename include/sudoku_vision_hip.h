@@ -233,7 +233,8 @@ typedef struct sv_jpeg_info {
     int h_samp, v_samp;             /* luma sampling factors: 1x1, 2x1 or 2x2 */
     int orientation;                /* EXIF tag 0x0112, 1..8 (1 when absent) */
     int restart_interval;           /* MCUs, 0 = none */
-    long coef_count;                /* int16 values sv_jpeg_entropy_decode writes */
+    long coef_count;                /* int16 values sv_jpeg_entropy_decode writes (64 per block) */
+    long sparse_capacity;           /* values sv_jpeg_entropy_decode_sparse may need room for (bound from the file size) */
 } sv_jpeg_info;
 
 int sv_jpeg_parse(const uint8_t *data /*host*/, size_t size, sv_jpeg_info *info);
@@ -242,12 +243,27 @@ int sv_jpeg_parse(const uint8_t *data /*host*/, size_t size, sv_jpeg_info *info)
  * block in natural (row-major, de-zigzagged) order; quant: 3 x 64 quantiser steps, natural order, per component. */
 int sv_jpeg_entropy_decode(const uint8_t *data /*host*/, size_t size, int16_t *coef /*host, coef_count*/,
                            uint16_t *quant /*host, 192*/, int threads);
-int sv_jpeg_entropy_decode_batch(const uint8_t *const *datas, const size_t *sizes, int n, int16_t *const *coefs /*host*/,
-                                 uint16_t *quants /*host, n*192*/, int threads, int *status /*n*/);
+/* The same in the compact form that crosses PCIe: per block (same block order) a 64-bit mask over ZIGZAG positions and the
+ * index of the block's first value; `values` receives the non-zero coefficients, zigzag order, block after block.  A q90
+ * 1080p frame is ~2 MB this way instead of 6.3 MB.  values_used: every index the masks/offsets refer to is below it (copy
+ * that prefix).  SV_ERR_BUFFER when values_cap < info.sparse_capacity turns out too small. */
+int sv_jpeg_entropy_decode_sparse(const uint8_t *data /*host*/, size_t size, uint64_t *masks /*host, coef_count/64*/,
+                                  uint32_t *offsets /*host, coef_count/64*/, int16_t *values /*host, values_cap*/,
+                                  long values_cap, long *values_used, uint16_t *quant /*host, 192*/, int threads);
+
+/* A batch of files over `threads` host threads.  Dense output when coefs != NULL (masks..values_used ignored), sparse output
+ * otherwise.  status[i] = per-image sv_status; returns the first failure. */
+int sv_jpeg_entropy_decode_batch(const uint8_t *const *datas, const size_t *sizes, int n, int16_t *const *coefs /*host or NULL*/,
+                                 uint64_t *const *masks, uint32_t *const *offsets, int16_t *const *values,
+                                 const long *values_cap, long *values_used, uint16_t *quants /*host, n*192*/,
+                                 int threads, int *status /*n*/);
 
 /* Device half: coefficients -> BGR frame (out_height x out_width x 3, row pitch `pitch` bytes), asynchronous on `stream`. */
 int sv_jpeg_reconstruct_bgr_u8(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef /*dev*/,
                                const uint16_t *quant /*dev, 192*/, uint8_t *bgr /*dev*/, ptrdiff_t pitch, void *stream);
+int sv_jpeg_reconstruct_sparse_bgr_u8(sv_ctx *ctx, const sv_jpeg_info *info, const uint64_t *masks /*dev*/,
+                                      const uint32_t *offsets /*dev*/, const int16_t *values /*dev*/,
+                                      const uint16_t *quant /*dev, 192*/, uint8_t *bgr /*dev*/, ptrdiff_t pitch, void *stream);
 
 /* ---- the whole device-resident path ----------------------------------------------------------- */
 

@@ -44,8 +44,10 @@ SIGNATURES = {
     "sv_preprocess_cells_u8": [_p, _p, _l, _p, _p],
     "sv_jpeg_parse": [_p, C.c_size_t, _p],
     "sv_jpeg_entropy_decode": [_p, C.c_size_t, _p, _p, _i],
-    "sv_jpeg_entropy_decode_batch": [_p, _p, _i, _p, _p, _i, _p],
+    "sv_jpeg_entropy_decode_sparse": [_p, C.c_size_t, _p, _p, _p, _l, _p, _p, _i],
+    "sv_jpeg_entropy_decode_batch": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "sv_jpeg_reconstruct_bgr_u8": [_p, _p, _p, _p, _p, _pd, _p],
+    "sv_jpeg_reconstruct_sparse_bgr_u8": [_p, _p, _p, _p, _p, _p, _p, _pd, _p],
     "sv_softmax_topk_f32": [_p, _p, _l, _i, _p, _p, _p],
     "sv_cnn_forward_f32": [_p, _p, _l, _p, _p, _p, _p],
     "sv_cnn_forward_cells_u8": [_p, _p, _l, _i, _p, _p, _p, _p],
@@ -58,7 +60,7 @@ _RESTYPES = {"sv_last_error": C.c_char_p}
 class JpegInfo(C.Structure):
     """sv_jpeg_info of include/sudoku_vision_hip.h"""
     _fields_ = [(n, C.c_int) for n in ("width", "height", "out_width", "out_height", "components", "h_samp", "v_samp",
-                                        "orientation", "restart_interval")] + [("coef_count", C.c_long)]
+                                        "orientation", "restart_interval")] + [("coef_count", C.c_long), ("sparse_capacity", C.c_long)]
 
 
 _lib = None

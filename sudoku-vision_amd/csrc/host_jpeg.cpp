@@ -222,8 +222,11 @@ scanned:
     return SV_OK;
 }
 
-void export_info(const Header &h, sv_jpeg_info *o)
+long sparse_capacity(const Header &h, size_t size);
+
+void export_info(const Header &h, size_t size, sv_jpeg_info *o)
 {
+    o->sparse_capacity = sparse_capacity(h, size);
     const bool swap = h.orientation >= 5;
     o->width = h.width; o->height = h.height;
     o->out_width = swap ? h.height : h.width; o->out_height = swap ? h.width : h.height;
@@ -291,8 +294,16 @@ struct Scan {
     int mcu_cols = 0, mcu_rows = 0;
 };
 
-// Decodes MCUs [m0, m1) of a scan from one restart interval's bytes
-void decode_interval(const Header &h, const Scan &scan, const uint8_t *b, const uint8_t *e, long m0, long m1, int16_t *coef)
+// Where decoded blocks go.  Dense: 64 int16 per block, natural order.  Sparse (the PCIe transport): per block a 64-bit
+// mask over ZIGZAG positions and the index of its first value; the non-zero values themselves are appended, in zigzag order,
+// to a value stream -- a q90 1080p frame is ~0.6 M values + 12 B per block instead of 3.1 M int16.
+struct DenseOut { int16_t *coef; };
+struct SparseOut { uint64_t *masks; uint32_t *offs; int16_t *vals; };
+
+// Decodes MCUs [m0, m1) of a scan from one restart interval's bytes.  Sparse: values are appended from index `vpos` on;
+// returns the index after the last value written (dense: 0).
+template <bool SPARSE, class Out>
+long decode_interval(const Header &h, const Scan &scan, const uint8_t *b, const uint8_t *e, long m0, long m1, const Out &out, long vpos)
 {
     BitStream bs(b, e);
     int pred[3] = {0, 0, 0};
@@ -304,37 +315,52 @@ void decode_interval(const Header &h, const Scan &scan, const uint8_t *b, const 
             const HuffTable &dct = h.dc[s.dc], &act = h.ac[s.ac];
             for (int v = 0; v < s.nv; v++)
                 for (int u = 0; u < s.nh; u++) {
-                    int16_t *blk = coef + c.offset + ((long)(my * s.nv + v) * c.bw + (mx * s.nh + u)) * 64;
-                    memset(blk, 0, 64 * sizeof(int16_t));           // cleared while the lines are about to be written anyway
+                    const long bi = c.offset / 64 + (long)(my * s.nv + v) * c.bw + (mx * s.nh + u);
+                    int16_t *blk = nullptr;
+                    uint64_t mask = 0;
+                    const long vstart = vpos;
+                    if constexpr (!SPARSE) {
+                        blk = out.coef + bi * 64;
+                        memset(blk, 0, 64 * sizeof(int16_t));       // cleared while the lines are about to be written anyway
+                    }
                     bs.refill();
                     const int t = bs.symbol(dct) & 15;
                     if (t) pred[i] += bs.take_signed(t);
-                    blk[0] = (int16_t)pred[i];
+                    if constexpr (SPARSE) { if ((int16_t)pred[i]) { mask = 1; out.vals[vpos++] = (int16_t)pred[i]; } }
+                    else blk[0] = (int16_t)pred[i];
                     for (int k = 1; k < 64;) {
                         bs.refill();
                         const int32_t f = act.fast_ac[bs.peek16() >> (16 - kLook)];
+                        int val;
                         if (f) {
                             k += (f >> 8) & 15;
                             if (k > 63) break;
                             bs.drop(f & 255);
-                            blk[kNatural[k++]] = (int16_t)(f >> 16);
-                            continue;
+                            val = f >> 16;
+                        } else {
+                            const int rs = bs.symbol(act), run = rs >> 4, size = rs & 15;
+                            if (size == 0) {
+                                if (run != 15) break;               // EOB
+                                k += 16;
+                                continue;
+                            }
+                            k += run;
+                            if (k > 63) break;
+                            val = bs.take_signed(size);
                         }
-                        const int rs = bs.symbol(act), run = rs >> 4, size = rs & 15;
-                        if (size == 0) {
-                            if (run != 15) break;                   // EOB
-                            k += 16;
-                            continue;
-                        }
-                        k += run;
-                        if (k > 63) break;
-                        blk[kNatural[k]] = (int16_t)bs.take_signed(size);
+                        if constexpr (SPARSE) { if ((int16_t)val) { mask |= 1ull << k; out.vals[vpos++] = (int16_t)val; } }
+                        else blk[kNatural[k]] = (int16_t)val;
                         k++;
                     }
+                    if constexpr (SPARSE) { out.masks[bi] = mask; out.offs[bi] = (uint32_t)vstart; }
                 }
         }
     }
+    return vpos;
 }
+
+// every non-zero value costs at least 2 bits (code >= 1, magnitude >= 1): an interval of n bytes holds at most 4n values
+inline long interval_value_bound(size_t bytes) { return 4 * (long)bytes + 2; }
 
 // Splits the entropy-coded bytes that start at `pos` into restart intervals; returns the offset of the marker that ends the scan
 size_t split_intervals(const uint8_t *d, size_t size, size_t pos, std::vector<std::pair<size_t, size_t>> &out)
@@ -353,11 +379,13 @@ size_t split_intervals(const uint8_t *d, size_t size, size_t pos, std::vector<st
     }
 }
 
-int entropy_decode(const uint8_t *d, size_t size, Header &h, int16_t *coef, int threads)
+template <bool SPARSE, class Out>
+int entropy_decode(const uint8_t *d, size_t size, Header &h, const Out &out, int threads, long vals_cap, long *vals_used)
 {
-    bool cleared = false;                                          // interleaved scans clear each block as they reach it
+    bool cleared = false;                                          // interleaved scans reach (and clear) every block
     size_t pos = h.first_scan;
     int covered = 0;
+    long vbase = 0;                                                // sparse: where the next scan's value regions start
     while (covered < h.ncomp) {
         const uint8_t *s;
         int n;
@@ -380,7 +408,8 @@ int entropy_decode(const uint8_t *d, size_t size, Header &h, int16_t *coef, int 
         if (tail[0] != 0 || tail[1] != 63 || tail[2] != 0) return sv_fail(SV_ERR_UNSUPPORTED, "jpeg: spectral selection / successive approximation in a sequential file");
         if (scan.ns == 1) {                                        // non-interleaved: the component's own block grid
             if (h.ncomp > 1 && !cleared) {                         // ... which does not reach the MCU padding blocks
-                memset(coef, 0, (size_t)h.coef_count * sizeof(int16_t));
+                if constexpr (SPARSE) memset(out.masks, 0, (size_t)(h.coef_count / 64) * sizeof(uint64_t));
+                else memset(out.coef, 0, (size_t)h.coef_count * sizeof(int16_t));
                 cleared = true;
             }
             const Component &c = h.comp[scan.sc[0].comp];
@@ -393,14 +422,46 @@ int entropy_decode(const uint8_t *d, size_t size, Header &h, int16_t *coef, int 
         const long per = h.restart_interval > 0 ? h.restart_interval : nmcu;
         const long need = (nmcu + per - 1) / per;
         if ((long)iv.size() < need) return sv_fail(SV_ERR_BAD_ARG, "jpeg: %ld restart intervals found, %ld needed (truncated file?)", (long)iv.size(), need);
+        std::vector<long> vstart((size_t)need + 1, 0), vend((size_t)need, 0);
+        if constexpr (SPARSE) {                                    // each interval appends to its own stretch of the value stream
+            vstart[0] = vbase;
+            for (long k = 0; k < need; k++) {
+                long blocks = 0;
+                for (int i = 0; i < scan.ns; i++) blocks += (long)scan.sc[i].nh * scan.sc[i].nv;
+                const long m0 = k * per, m1 = std::min(nmcu, m0 + per);
+                vstart[k + 1] = vstart[k] + std::min(interval_value_bound(iv[k].second - iv[k].first), (m1 - m0) * blocks * 64);
+            }
+            if (vstart[need] > vals_cap) return sv_fail(SV_ERR_BUFFER, "jpeg: value buffer holds %ld, this file may need %ld", vals_cap, vstart[need]);
+        }
         const Header &hc = h;
         WorkerPool::instance().parallel_for((int)need, threads, [&](int k) {
             const long m0 = (long)k * per, m1 = std::min(nmcu, m0 + per);
-            decode_interval(hc, scan, d + iv[k].first, d + iv[k].second, m0, m1, coef);
+            vend[k] = decode_interval<SPARSE>(hc, scan, d + iv[k].first, d + iv[k].second, m0, m1, out, vstart[k]);
         });
+        if constexpr (SPARSE) {
+            vbase = vstart[need];
+            if (vals_used) *vals_used = vend[need - 1];            // everything the kernels can reference lies below this index
+        }
         covered += scan.ns;
     }
     return SV_OK;
+}
+
+int fill_quant(const Header &h, uint16_t *quant)
+{
+    memset(quant, 0, 3 * 64 * sizeof(uint16_t));
+    for (int c = 0; c < h.ncomp; c++) {
+        if (!h.quant_defined[h.comp[c].tq]) return sv_fail(SV_ERR_BAD_ARG, "jpeg: component %d uses an undefined quantisation table", c);
+        memcpy(quant + 64 * c, h.quant[h.comp[c].tq], 64 * sizeof(uint16_t));
+    }
+    return SV_OK;
+}
+
+long sparse_capacity(const Header &h, size_t size)
+{
+    const long nmcu = (long)h.mcu_cols * h.mcu_rows;
+    const long intervals = h.restart_interval > 0 ? (nmcu + h.restart_interval - 1) / h.restart_interval : 1;
+    return std::min(h.coef_count, 4 * (long)size + 2 * 3 * intervals + 64);
 }
 
 }  // namespace
@@ -412,7 +473,7 @@ extern "C" int sv_jpeg_parse(const uint8_t *data, size_t size, sv_jpeg_info *inf
     std::unique_ptr<Header> h(new Header);
     const int rc = parse_header(data, size, *h);
     if (rc) return rc;
-    export_info(*h, info);
+    export_info(*h, size, info);
     return SV_OK;
 }
 
@@ -421,43 +482,48 @@ extern "C" int sv_jpeg_entropy_decode(const uint8_t *data, size_t size, int16_t 
     if (!data || !coef || !quant) return sv_fail(SV_ERR_BAD_ARG, "sv_jpeg_entropy_decode: NULL argument");
     std::unique_ptr<Header> h(new Header);
     int rc = parse_header(data, size, *h);
-    if (rc) return rc;
-    memset(quant, 0, 3 * 64 * sizeof(uint16_t));
-    for (int c = 0; c < h->ncomp; c++) {
-        if (!h->quant_defined[h->comp[c].tq]) return sv_fail(SV_ERR_BAD_ARG, "jpeg: component %d uses an undefined quantisation table", c);
-        memcpy(quant + 64 * c, h->quant[h->comp[c].tq], 64 * sizeof(uint16_t));
-    }
-    return entropy_decode(data, size, *h, coef, threads < 1 ? 1 : threads);
+    if (rc || (rc = fill_quant(*h, quant))) return rc;
+    return entropy_decode<false>(data, size, *h, DenseOut{coef}, threads < 1 ? 1 : threads, 0, nullptr);
 }
 
-extern "C" int sv_jpeg_entropy_decode_batch(const uint8_t *const *datas, const size_t *sizes, int n, int16_t *const *coefs, uint16_t *quants, int threads, int *status)
+extern "C" int sv_jpeg_entropy_decode_sparse(const uint8_t *data, size_t size, uint64_t *masks, uint32_t *offsets, int16_t *values, long values_cap,
+                                             long *values_used, uint16_t *quant, int threads)
 {
-    if (!datas || !sizes || !coefs || !quants || !status || n <= 0) return sv_fail(SV_ERR_BAD_ARG, "sv_jpeg_entropy_decode_batch: bad argument");
+    if (!data || !masks || !offsets || !values || !values_used || !quant) return sv_fail(SV_ERR_BAD_ARG, "sv_jpeg_entropy_decode_sparse: NULL argument");
+    std::unique_ptr<Header> h(new Header);
+    int rc = parse_header(data, size, *h);
+    if (rc || (rc = fill_quant(*h, quant))) return rc;
+    *values_used = 0;
+    return entropy_decode<true>(data, size, *h, SparseOut{masks, offsets, values}, threads < 1 ? 1 : threads, values_cap, values_used);
+}
+
+// Images of a batch over the pool's threads; every image decodes its restart intervals serially (a worker's nested
+// parallel_for runs inline).  Dense when `coefs` is given, sparse when masks/offsets/values are.
+extern "C" int sv_jpeg_entropy_decode_batch(const uint8_t *const *datas, const size_t *sizes, int n, int16_t *const *coefs, uint64_t *const *masks,
+                                            uint32_t *const *offsets, int16_t *const *values, const long *values_cap, long *values_used,
+                                            uint16_t *quants, int threads, int *status)
+{
+    const bool sparse = coefs == nullptr;
+    if (!datas || !sizes || !quants || !status || n <= 0 || (sparse && (!masks || !offsets || !values || !values_cap || !values_used)))
+        return sv_fail(SV_ERR_BAD_ARG, "sv_jpeg_entropy_decode_batch: bad argument");
     if (threads < 1) threads = 1;
-    // images over threads; every image decodes its own restart intervals serially (nested parallel_for is not re-entrant)
-    int first_bad = SV_OK;
     std::vector<std::unique_ptr<Header>> hs((size_t)n);
-    for (int i = 0; i < n; i++) {
+    auto one = [&](int i, int inner_threads) {
         hs[i].reset(new Header);
-        status[i] = (datas[i] && coefs[i]) ? parse_header(datas[i], sizes[i], *hs[i]) : SV_ERR_BAD_ARG;
-        if (status[i] == SV_OK) {
-            uint16_t *q = quants + 192 * (size_t)i;
-            memset(q, 0, 192 * sizeof(uint16_t));
-            for (int c = 0; c < hs[i]->ncomp; c++) {
-                if (!hs[i]->quant_defined[hs[i]->comp[c].tq]) { status[i] = SV_ERR_BAD_ARG; break; }
-                memcpy(q + 64 * c, hs[i]->quant[hs[i]->comp[c].tq], 128);
-            }
+        const bool ok = datas[i] && (sparse ? (masks[i] && offsets[i] && values[i]) : coefs[i] != nullptr);
+        int rc = ok ? parse_header(datas[i], sizes[i], *hs[i]) : SV_ERR_BAD_ARG;
+        if (!rc) rc = fill_quant(*hs[i], quants + 192 * (size_t)i);
+        if (!rc) {
+            if (sparse) {
+                values_used[i] = 0;
+                rc = entropy_decode<true>(datas[i], sizes[i], *hs[i], SparseOut{masks[i], offsets[i], values[i]}, inner_threads, values_cap[i], values_used + i);
+            } else rc = entropy_decode<false>(datas[i], sizes[i], *hs[i], DenseOut{coefs[i]}, inner_threads, 0, nullptr);
         }
-    }
-    if (threads == 1 || n == 1) {
-        for (int i = 0; i < n; i++)
-            if (status[i] == SV_OK) status[i] = entropy_decode(datas[i], sizes[i], *hs[i], coefs[i], n == 1 ? threads : 1);
-    } else {
-        // the pool's workers call entropy_decode with threads = 1, which runs its parallel_for inline
-        WorkerPool::instance().parallel_for(n, threads, [&](int i) {
-            if (status[i] == SV_OK) status[i] = entropy_decode(datas[i], sizes[i], *hs[i], coefs[i], 1);
-        });
-    }
-    for (int i = 0; i < n; i++) if (status[i] != SV_OK && first_bad == SV_OK) first_bad = status[i];
-    return first_bad == SV_OK ? SV_OK : sv_fail(first_bad, "sv_jpeg_entropy_decode_batch: at least one image failed (see status[])");
+        status[i] = rc;
+    };
+    if (threads == 1 || n == 1) for (int i = 0; i < n; i++) one(i, n == 1 ? threads : 1);
+    else WorkerPool::instance().parallel_for(n, threads, [&](int i) { one(i, 1); });
+    for (int i = 0; i < n; i++)
+        if (status[i] != SV_OK) return sv_fail(status[i], "sv_jpeg_entropy_decode_batch: image %d failed (see status[])", i);
+    return SV_OK;
 }

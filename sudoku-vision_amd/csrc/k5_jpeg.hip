@@ -52,8 +52,16 @@ __device__ __forceinline__ void idct8(const int (&in)[8], int (&out)[8])
     out[3] = tmp13 + tmp0; out[4] = tmp13 - tmp0;
 }
 
-__global__ __launch_bounds__(256) void k_jpeg_idct(const short *__restrict__ coef, const unsigned short *__restrict__ quant, JpegGeom g,
-                                                    u8 *__restrict__ planes)
+// natural (row-major) position -> zigzag index
+__constant__ unsigned char kZigzagOf[64] = {0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+                                            10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+// SPARSE: the block arrives as (mask over zigzag positions, offset of its first value) + the packed value stream; a thread
+// picks its row's eight coefficients by rank: value index = offset + popcount(mask below the position's zigzag bit).
+template <bool SPARSE>
+__global__ __launch_bounds__(256) void k_jpeg_idct(const short *__restrict__ coef, const unsigned long long *__restrict__ masks,
+                                                    const unsigned *__restrict__ offsets, const short *__restrict__ values,
+                                                    const unsigned short *__restrict__ quant, JpegGeom g, u8 *__restrict__ planes)
 {
     __shared__ int ws[32][8][9];
     const int tid = threadIdx.x, b = tid >> 3, r = tid & 7;
@@ -63,13 +71,28 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const short *__restrict__ coe
     if (live) { if (blk >= g.blk_start[1]) c = 1; if (blk >= g.blk_start[2]) c = 2; }
     const long lb = blk - g.blk_start[c];                       // block index within the component
     if (live) {
-        const int4 raw = *(const int4 *)(coef + g.coef_off[c] + lb * 64 + r * 8);
         const int4 qr = *(const int4 *)(quant + c * 64 + r * 8);
-        const int cw[4] = {raw.x, raw.y, raw.z, raw.w}, qw[4] = {qr.x, qr.y, qr.z, qr.w};
+        const int qw[4] = {qr.x, qr.y, qr.z, qr.w};
+        if (SPARSE) {
+            const long gb = g.coef_off[c] / 64 + lb;            // block index over all components
+            const unsigned long long mask = masks[gb];
+            const short *v = values + offsets[gb];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            ws[b][r][2 * i] = (int)(short)(cw[i] & 0xffff) * (int)(qw[i] & 0xffff);
-            ws[b][r][2 * i + 1] = (cw[i] >> 16) * (int)((unsigned)qw[i] >> 16);
+            for (int i = 0; i < 8; i++) {
+                const int z = kZigzagOf[r * 8 + i];
+                const int q = (i & 1) ? (int)((unsigned)qw[i >> 1] >> 16) : (int)(qw[i >> 1] & 0xffff);
+                int val = 0;
+                if ((mask >> z) & 1) val = v[__popcll(mask & ((1ull << z) - 1))];
+                ws[b][r][i] = val * q;
+            }
+        } else {
+            const int4 raw = *(const int4 *)(coef + g.coef_off[c] + lb * 64 + r * 8);
+            const int cw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ws[b][r][2 * i] = (int)(short)(cw[i] & 0xffff) * (int)(qw[i] & 0xffff);
+                ws[b][r][2 * i + 1] = (cw[i] >> 16) * (int)((unsigned)qw[i] >> 16);
+            }
         }
     }
     __syncthreads();
@@ -153,7 +176,8 @@ __global__ __launch_bounds__(256) void k_jpeg_colour(const u8 *__restrict__ plan
 
 }  // namespace
 
-int svk_jpeg_reconstruct(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint16_t *quant, u8 *bgr, ptrdiff_t pitch, hipStream_t s)
+int svk_jpeg_reconstruct(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint64_t *masks, const uint32_t *offsets, const int16_t *values,
+                         const uint16_t *quant, u8 *bgr, ptrdiff_t pitch, hipStream_t s)
 {
     JpegGeom g;
     g.ncomp = info->components; g.W = info->width; g.H = info->height; g.OW = info->out_width; g.OH = info->out_height;
@@ -178,7 +202,11 @@ int svk_jpeg_reconstruct(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *c
         SV_HIP(hipMalloc((void **)&ctx->jpeg_planes, (size_t)poff));
         ctx->cap_jpeg = (size_t)poff;
     }
-    hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((blocks + 31) / 32)), dim3(256), 0, s, (const short *)coef, quant, g, ctx->jpeg_planes);
+    if (coef)
+        hipLaunchKernelGGL(k_jpeg_idct<false>, dim3((unsigned)((blocks + 31) / 32)), dim3(256), 0, s, (const short *)coef, nullptr, nullptr, nullptr, quant, g, ctx->jpeg_planes);
+    else
+        hipLaunchKernelGGL(k_jpeg_idct<true>, dim3((unsigned)((blocks + 31) / 32)), dim3(256), 0, s, nullptr, (const unsigned long long *)masks, offsets, (const short *)values, quant, g,
+                           ctx->jpeg_planes);
     SV_LAUNCH_CHECK("k_jpeg_idct");
     hipLaunchKernelGGL(k_jpeg_colour, dim3((unsigned)((g.OW + 255) / 256), (unsigned)g.OH), dim3(256), 0, s, ctx->jpeg_planes, g, bgr, (long)pitch);
     SV_LAUNCH_CHECK("k_jpeg_colour");

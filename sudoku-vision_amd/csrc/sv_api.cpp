@@ -485,18 +485,36 @@ extern "C" int sv_softmax_topk_f32(sv_ctx *ctx, const float *logits, long B, int
     return svk_softmax_topk(logits, B, k, index, prob, S(stream));
 }
 
+static int jpeg_info_ok(const sv_jpeg_info *info, ptrdiff_t pitch, const char *fn)
+{
+    const char *what = nullptr;
+    const bool swap = info->orientation >= 5;
+    if (!(info->width > 0 && info->height > 0 && info->width < 65536 && info->height < 65536)) what = "bad image size";
+    else if (!(info->components == 1 || info->components == 3)) what = "components must be 1 or 3";
+    else if (!((info->h_samp == 1 && info->v_samp == 1) || (info->h_samp == 2 && (info->v_samp == 1 || info->v_samp == 2)))) what = "sampling must be 1x1, 2x1 or 2x2";
+    else if (!(info->orientation >= 1 && info->orientation <= 8)) what = "orientation must be 1..8";
+    else if (!(info->out_width == (swap ? info->height : info->width) && info->out_height == (swap ? info->width : info->height))) what = "out_width/out_height do not match the orientation";
+    else if (pitch < 3 * (ptrdiff_t)info->out_width) what = "pitch smaller than a row";
+    return what ? sv_fail(SV_ERR_BAD_ARG, "%s: %s", fn, what) : SV_OK;
+}
+
 extern "C" int sv_jpeg_reconstruct_bgr_u8(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint16_t *quant, uint8_t *bgr, ptrdiff_t pitch, void *stream)
 {
     REQUIRE(ctx && info && coef && quant && bgr, "NULL argument");
-    REQUIRE(info->width > 0 && info->height > 0 && info->width < 65536 && info->height < 65536, "bad image size");
-    REQUIRE(info->components == 1 || info->components == 3, "components must be 1 or 3");
-    REQUIRE((info->h_samp == 1 && info->v_samp == 1) || (info->h_samp == 2 && (info->v_samp == 1 || info->v_samp == 2)), "sampling must be 1x1, 2x1 or 2x2");
-    REQUIRE(info->orientation >= 1 && info->orientation <= 8, "orientation must be 1..8");
-    const bool swap = info->orientation >= 5;
-    REQUIRE(info->out_width == (swap ? info->height : info->width) && info->out_height == (swap ? info->width : info->height), "out_width/out_height do not match the orientation");
-    REQUIRE(pitch >= 3 * (ptrdiff_t)info->out_width, "pitch smaller than a row");
+    const int rc = jpeg_info_ok(info, pitch, "sv_jpeg_reconstruct_bgr_u8");
+    if (rc) return rc;
     REQUIRE(((uintptr_t)coef & 15) == 0 && ((uintptr_t)quant & 15) == 0, "coef and quant must be 16-byte aligned");
-    return svk_jpeg_reconstruct(ctx, info, coef, quant, bgr, pitch, S(stream));
+    return svk_jpeg_reconstruct(ctx, info, coef, nullptr, nullptr, nullptr, quant, bgr, pitch, S(stream));
+}
+
+extern "C" int sv_jpeg_reconstruct_sparse_bgr_u8(sv_ctx *ctx, const sv_jpeg_info *info, const uint64_t *masks, const uint32_t *offsets, const int16_t *values,
+                                                 const uint16_t *quant, uint8_t *bgr, ptrdiff_t pitch, void *stream)
+{
+    REQUIRE(ctx && info && masks && offsets && values && quant && bgr, "NULL argument");
+    const int rc = jpeg_info_ok(info, pitch, "sv_jpeg_reconstruct_sparse_bgr_u8");
+    if (rc) return rc;
+    REQUIRE(((uintptr_t)masks & 7) == 0 && ((uintptr_t)offsets & 3) == 0 && ((uintptr_t)values & 1) == 0 && ((uintptr_t)quant & 15) == 0, "misaligned argument");
+    return svk_jpeg_reconstruct(ctx, info, nullptr, masks, offsets, values, quant, bgr, pitch, S(stream));
 }
 
 extern "C" int sv_frames_to_digits(sv_ctx *ctx, const uint8_t *frames, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t frame_stride, const double *minv, int glue, uint8_t *cells, float *logits, uint8_t *digits, float *conf, void *stream)

@@ -90,7 +90,8 @@ int svk_resize_linear(const u8 *src, int sh, int sw, ptrdiff_t pitch, u8 *dst, i
 int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8 *digits, float *conf, hipStream_t s);
 int svk_cell_ink_ratio(const u8 *cells, long B, int npx, float *ratio, int *otsu, hipStream_t s);
 int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s);
-int svk_jpeg_reconstruct(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint16_t *quant, u8 *bgr, ptrdiff_t pitch, hipStream_t s);
+int svk_jpeg_reconstruct(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint64_t *masks, const uint32_t *offsets, const int16_t *values,
+                         const uint16_t *quant, u8 *bgr, ptrdiff_t pitch, hipStream_t s);   // dense when coef != nullptr, else sparse
 int svk_softmax_topk(const float *logits, long B, int k, u8 *index, float *prob, hipStream_t s);
 
 // host helpers

@@ -136,3 +136,18 @@ def jpeg_entropy_decode(data: bytes, coef=None, quant=None, threads=1):
     _native.check(_native.lib().sv_jpeg_entropy_decode(data, len(data), coef.ctypes.data_as(C.c_void_p), quant.ctypes.data_as(C.c_void_p), int(threads)),
                   "sv_jpeg_entropy_decode")
     return info, coef, quant
+
+
+def jpeg_entropy_decode_sparse(data: bytes, threads=1):
+    """-> (info, masks uint64 [blocks], offsets uint32 [blocks], values int16 [used], quant uint16 [3,64]): the compact
+    transport form (mask over zigzag positions + first-value index per block, non-zero values in zigzag order)."""
+    info = jpeg_parse(data)
+    nb = info.coef_count // 64
+    masks, offs = np.empty(nb, np.uint64), np.empty(nb, np.uint32)
+    vals = np.empty(info.sparse_capacity, np.int16)
+    quant = np.empty((3, 64), np.uint16)
+    used = C.c_long()
+    _native.check(_native.lib().sv_jpeg_entropy_decode_sparse(data, len(data), masks.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
+                                                              vals.ctypes.data_as(C.c_void_p), vals.size, C.byref(used), quant.ctypes.data_as(C.c_void_p), int(threads)),
+                  "sv_jpeg_entropy_decode_sparse")
+    return info, masks, offs, vals[:used.value], quant

@@ -178,65 +178,114 @@ class Context:
                       "sv_cell_ink_ratio_u8")
         return ratio, otsu
 
-    def imdecode(self, data: bytes, threads=1, out=None):
-        """cv2.imdecode / cv2.imread of a baseline JPEG -> BGR uint8 CUDA tensor [H,W,3] (EXIF orientation applied).
-        Huffman decoding on the host (csrc/host_jpeg.cpp) into a pinned staging buffer, everything after it on the GPU."""
-        from . import host
-        info = host.jpeg_parse(data)
-        n = int(info.coef_count)
-        if getattr(self, "_jpeg_pin", None) is None or self._jpeg_pin.numel() < n + 192 + 8:
-            self._jpeg_pin = torch.empty(n + 192 + 8, dtype=torch.int16).pin_memory()
-            self._jpeg_dev = torch.empty(n + 192 + 8, dtype=torch.int16, device=self.device)
-        else:
-            torch.cuda.current_stream(self.device).synchronize()      # the previous decode may still be reading the staging buffer
-        qoff = (n + 7) // 8 * 8                                         # keeps the quantiser block 16-byte aligned
-        pin = self._jpeg_pin.numpy()
-        host.jpeg_entropy_decode(data, coef=pin[:n], quant=pin[qoff:qoff + 192].view(np.uint16).reshape(3, 64), threads=threads)
-        self._jpeg_dev[:qoff + 192].copy_(self._jpeg_pin[:qoff + 192], non_blocking=True)
-        if out is None:
-            out = torch.empty((info.out_height, info.out_width, 3), dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_jpeg_reconstruct_bgr_u8(self._h, C.byref(info), _ptr(self._jpeg_dev), C.c_void_p(self._jpeg_dev.data_ptr() + 2 * qoff),
-                                                               _ptr(out), out.stride(0), _stream_ptr()), "sv_jpeg_reconstruct_bgr_u8")
-        return out
+    # ---- JPEG front end (scope row N4) -----------------------------------------------------------------
+    def _jpeg_staging(self, nbytes):
+        """Two pinned + device staging sets used alternately, so the H2D copy and reconstruction of one call overlap the
+        host Huffman decoding of the next.  Returns (pinned u8 tensor, device u8 tensor) of at least nbytes."""
+        if not hasattr(self, "_jpeg_sets"):
+            self._jpeg_sets, self._jpeg_turn = [None, None], 0
+        self._jpeg_turn ^= 1
+        cur = self._jpeg_sets[self._jpeg_turn]
+        if cur is not None:
+            cur[2].synchronize()                                       # the copy that last read this set has finished
+        if cur is None or cur[0].numel() < nbytes:
+            cap = int(nbytes * 1.25) + 4096
+            cur = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device), torch.cuda.Event()]
+            self._jpeg_sets[self._jpeg_turn] = cur
+        return cur
 
-    def imdecode_batch(self, datas, threads=16):
+    def imdecode_batch(self, datas, threads=16, dense=False):
         """A batch of JPEG files -> uint8 CUDA tensor [n,H,W,3] when all share a shape, else a list of [H,W,3] tensors.
-        Images are Huffman-decoded on `threads` host threads (sv_jpeg_entropy_decode_batch) into one pinned buffer, cross
-        PCIe in one copy, and are reconstructed on the GPU back to back."""
+        Images are Huffman-decoded on `threads` host threads (sv_jpeg_entropy_decode_batch) into pinned memory in the compact
+        mask + values form (dense=True: plain int16 blocks), cross PCIe one image per copy, and are reconstructed on the GPU
+        back to back.  Returns after the last launch; the next call's host decoding overlaps this call's copies and kernels."""
         from . import host
         n = len(datas)
         datas = [bytes(d) for d in datas]
         infos = [host.jpeg_parse(d) for d in datas]
-        offs, total = [], 0
+        lay, total = [], 0                                             # per image: (base, masks, offsets, values, capacity) byte offsets
         for info in infos:
-            offs.append(total)
-            total += (int(info.coef_count) + 7) // 8 * 8
+            nb = int(info.coef_count) // 64
+            base = total
+            if dense:
+                lay.append((base, 0, 0, base, int(info.coef_count)))
+                total += (2 * int(info.coef_count) + 63) // 64 * 64
+            else:
+                lay.append((base, base, base + 8 * nb, base + 12 * nb, int(info.sparse_capacity)))
+                total += (12 * nb + 2 * int(info.sparse_capacity) + 63) // 64 * 64
         qoff = total
-        total += 192 * n
-        if getattr(self, "_jpeg_pin", None) is None or self._jpeg_pin.numel() < total:
-            self._jpeg_pin = torch.empty(total, dtype=torch.int16).pin_memory()
-            self._jpeg_dev = torch.empty(total, dtype=torch.int16, device=self.device)
-        else:
-            torch.cuda.current_stream(self.device).synchronize()
-        base = self._jpeg_pin.data_ptr()
+        total += 384 * n
+        pin, dev, ev = self._jpeg_staging(total)
+        pb, db = pin.data_ptr(), dev.data_ptr()
+        VP = C.c_void_p * n
         bufs = (C.c_char_p * n)(*datas)
         sizes = (C.c_size_t * n)(*[len(d) for d in datas])
-        coefs = (C.c_void_p * n)(*[base + 2 * o for o in offs])
         status = (C.c_int * n)()
-        _native.check(_native.lib().sv_jpeg_entropy_decode_batch(bufs, sizes, n, coefs, C.c_void_p(base + 2 * qoff), int(threads), status),
+        used = (C.c_long * n)()
+        if dense:
+            args = (VP(*[pb + l[3] for l in lay]), None, None, None, None, None)
+        else:
+            args = (None, VP(*[pb + l[1] for l in lay]), VP(*[pb + l[2] for l in lay]), VP(*[pb + l[3] for l in lay]),
+                    (C.c_long * n)(*[l[4] for l in lay]), used)
+        _native.check(_native.lib().sv_jpeg_entropy_decode_batch(bufs, sizes, n, *args, C.c_void_p(pb + qoff), int(threads), status),
                       "sv_jpeg_entropy_decode_batch")
-        self._jpeg_dev[:total].copy_(self._jpeg_pin[:total], non_blocking=True)
         same = all((i.out_height, i.out_width) == (infos[0].out_height, infos[0].out_width) for i in infos)
         if same:
             out = torch.empty((n, infos[0].out_height, infos[0].out_width, 3), dtype=torch.uint8, device=self.device)
             outs = [out[i] for i in range(n)]
         else:
             outs = [torch.empty((i.out_height, i.out_width, 3), dtype=torch.uint8, device=self.device) for i in infos]
-        dbase = self._jpeg_dev.data_ptr()
-        for i in range(n):
-            _native.check(_native.lib().sv_jpeg_reconstruct_bgr_u8(self._h, C.byref(infos[i]), C.c_void_p(dbase + 2 * offs[i]), C.c_void_p(dbase + 2 * (qoff + 192 * i)),
-                                                                   _ptr(outs[i]), outs[i].stride(0), _stream_ptr()), "sv_jpeg_reconstruct_bgr_u8")
+        dev[qoff:qoff + 384 * n].copy_(pin[qoff:qoff + 384 * n], non_blocking=True)
+        lib, stream = _native.lib(), _stream_ptr()
+        for i, (info, l) in enumerate(zip(infos, lay)):
+            end = l[3] + 2 * (int(info.coef_count) if dense else used[i])
+            dev[l[0]:end].copy_(pin[l[0]:end], non_blocking=True)
+            q = C.c_void_p(db + qoff + 384 * i)
+            if dense:
+                rc = lib.sv_jpeg_reconstruct_bgr_u8(self._h, C.byref(info), C.c_void_p(db + l[3]), q, _ptr(outs[i]), outs[i].stride(0), stream)
+            else:
+                rc = lib.sv_jpeg_reconstruct_sparse_bgr_u8(self._h, C.byref(info), C.c_void_p(db + l[1]), C.c_void_p(db + l[2]), C.c_void_p(db + l[3]), q,
+                                                           _ptr(outs[i]), outs[i].stride(0), stream)
+            _native.check(rc, "sv_jpeg_reconstruct")
+        ev.record(torch.cuda.current_stream(self.device))
+        self._jpeg_last_bytes = sum((l[3] - l[0]) + 2 * (int(i.coef_count) if dense else used[k]) for k, (i, l) in enumerate(zip(infos, lay))) / max(n, 1)
         return out if same else outs
+
+    def imdecode(self, data: bytes, threads=1, out=None, dense=False):
+        """cv2.imdecode / cv2.imread of a baseline JPEG -> BGR uint8 CUDA tensor [H,W,3] (EXIF orientation applied).
+        Huffman decoding on the host (csrc/host_jpeg.cpp; `threads` work on restart intervals when the file has them) into
+        pinned staging memory, everything after it on the GPU."""
+        if out is None and threads <= 1:
+            return self.imdecode_batch([data], 1, dense=dense)[0]
+        from . import host
+        data = bytes(data)
+        info = host.jpeg_parse(data)
+        nb, ncoef, cap = int(info.coef_count) // 64, int(info.coef_count), int(info.sparse_capacity)
+        voff = 0 if dense else 12 * nb
+        qoff = (voff + 2 * (ncoef if dense else cap) + 63) // 64 * 64
+        pin, dev, ev = self._jpeg_staging(qoff + 384)
+        pb, db = pin.data_ptr(), dev.data_ptr()
+        lib = _native.lib()
+        if dense:
+            _native.check(lib.sv_jpeg_entropy_decode(data, len(data), C.c_void_p(pb), C.c_void_p(pb + qoff), int(threads)), "sv_jpeg_entropy_decode")
+            end = 2 * ncoef
+        else:
+            used = C.c_long()
+            _native.check(lib.sv_jpeg_entropy_decode_sparse(data, len(data), C.c_void_p(pb), C.c_void_p(pb + 8 * nb), C.c_void_p(pb + voff), cap, C.byref(used),
+                                                            C.c_void_p(pb + qoff), int(threads)), "sv_jpeg_entropy_decode_sparse")
+            end = voff + 2 * used.value
+        dev[:end].copy_(pin[:end], non_blocking=True)
+        dev[qoff:qoff + 384].copy_(pin[qoff:qoff + 384], non_blocking=True)
+        if out is None:
+            out = torch.empty((info.out_height, info.out_width, 3), dtype=torch.uint8, device=self.device)
+        if dense:
+            rc = lib.sv_jpeg_reconstruct_bgr_u8(self._h, C.byref(info), C.c_void_p(db), C.c_void_p(db + qoff), _ptr(out), out.stride(0), _stream_ptr())
+        else:
+            rc = lib.sv_jpeg_reconstruct_sparse_bgr_u8(self._h, C.byref(info), C.c_void_p(db), C.c_void_p(db + 8 * nb), C.c_void_p(db + voff), C.c_void_p(db + qoff),
+                                                       _ptr(out), out.stride(0), _stream_ptr())
+        _native.check(rc, "sv_jpeg_reconstruct")
+        ev.record(torch.cuda.current_stream(self.device))
+        return out
 
     def softmax_topk(self, logits, k=3):
         """F.softmax(logits, 1).topk(k) (pipeline/run_v2.py:165-178): (index u8 [B,k], prob f32 [B,k]), best first."""

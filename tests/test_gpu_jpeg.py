@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("h,w,kw", CASES)
 def test_imdecode_bit_exact(ctx, h, w, kw):
     data = encode(synth_image(h, w, h * 131 + w), **kw)
-    got = ctx.imdecode(data, threads=2).cpu().numpy()
-    assert (got == o.imdecode(data)).all()
-    assert (got == pil_bgr(data)).all()
+    want = pil_bgr(data)
+    assert (want == o.imdecode(data)).all()
+    for dense in (False, True):                                   # compact (mask + values) and plain int16 transport
+        for threads in (1, 2):
+            assert (ctx.imdecode(data, threads=threads, dense=dense).cpu().numpy() == want).all(), (dense, threads)
 
 
 def test_imdecode_gray_and_orientations(ctx):
@@ -67,8 +69,26 @@ def test_imread_conventions(ctx, tmp_path):
 
 
 def test_imdecode_back_to_back(ctx):
-    """The pinned staging buffer is reused: consecutive decodes of different sizes must not trample each other."""
-    datas = [encode(synth_image(h, w, h + w), quality=85, subsampling=2) for h, w in ((200, 300), (64, 64), (333, 222))]
+    """The two pinned staging sets alternate: consecutive decodes of different sizes must not trample each other."""
+    datas = [encode(synth_image(h, w, h + w), quality=85, subsampling=2) for h, w in ((200, 300), (64, 64), (333, 222), (90, 500), (512, 512))]
     outs = [ctx.imdecode(d) for d in datas]
     for d, t in zip(datas, outs):
         assert (t.cpu().numpy() == pil_bgr(d)).all()
+
+
+def test_imdecode_batch(ctx):
+    """Batch entry: same-shape files -> one [n,H,W,3] tensor, mixed shapes -> a list; both transports; a bad file fails loudly."""
+    import sudoku_vision_amd as sva
+    same = [encode(synth_image(144, 256, s), quality=60 + 10 * s, subsampling=2) for s in range(4)]
+    for dense in (False, True):
+        out = ctx.imdecode_batch(same, threads=3, dense=dense)
+        assert tuple(out.shape) == (4, 144, 256, 3)
+        for d, t in zip(same, out):
+            assert (t.cpu().numpy() == pil_bgr(d)).all()
+    mixed = [encode(synth_image(h, w, h), quality=80, subsampling=sub) for h, w, sub in ((50, 70, 0), (33, 97, 1), (128, 64, 2))]
+    outs = ctx.imdecode_batch(mixed, threads=2)
+    assert isinstance(outs, list)
+    for d, t in zip(mixed, outs):
+        assert (t.cpu().numpy() == pil_bgr(d)).all()
+    with pytest.raises(sva._native.NativeError):
+        ctx.imdecode_batch([same[0], b"\xff\xd8 this is not a jpeg"], threads=2)

@@ -129,7 +129,24 @@ def host():
 
 
 def _same_info(a, b):
-    return all(getattr(a, f) == getattr(b, f) for f, _ in type(a)._fields_)
+    """product sv_jpeg_info vs the oracle's (which has no sparse_capacity)"""
+    return all(getattr(a, f) == getattr(b, f) for f, _ in type(b)._fields_)
+
+
+_ZZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _densify(info, masks, offs, vals):
+    """The compact transport form back to dense natural-order blocks (what the GPU kernel does by popcount rank)."""
+    out = np.zeros(info.coef_count, np.int16)
+    for b in range(len(masks)):
+        m, k = int(masks[b]), int(offs[b])
+        for z in range(64):
+            if (m >> z) & 1:
+                out[b * 64 + _ZZ[z]] = vals[k]
+                k += 1
+    return out
 
 
 @pytest.mark.parametrize("h,w,kw", CASES)
@@ -139,6 +156,11 @@ def test_host_entropy_decode_matches_oracle(host, h, w, kw):
     assert _same_info(info, o.jpeg_info(data))
     oc, oq = o.jpeg_coefficients(data)
     assert (coef == oc).all() and (quant == oq).all()
+    # the compact (mask + values) form carries the same coefficients, within the capacity the header promised
+    info2, masks, offs, vals, quant2 = host.jpeg_entropy_decode_sparse(data, threads=3)
+    assert len(vals) <= info2.sparse_capacity <= info2.coef_count and (quant2 == oq).all()
+    assert (_densify(info2, masks, offs, vals) == oc).all()
+    assert int(sum(bin(int(m)).count("1") for m in masks)) == int(np.count_nonzero(oc))
 
 
 def test_host_entropy_decode_gray_orientation_photo(host):

@@ -5,7 +5,7 @@ import csv
 import glob
 import sys
 
-f = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
+f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in csv.DictReader(open(f)):

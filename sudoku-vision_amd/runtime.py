@@ -28,6 +28,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _frame_layout(frames):
+    """frames u8 [n,H,W,3]: (tensor, row pitch, frame stride) in bytes.  Row padding and gaps between frames are passed through to
+    the library (camera buffers are rarely dense); anything else is made contiguous first."""
+    if frames.dim() != 4 or frames.shape[3] != 3 or frames.dtype != torch.uint8:
+        raise TypeError("expected a uint8 tensor of shape [n,H,W,3]")
+    n, H, W, _ = frames.shape
+    st = frames.stride()
+    ok = st[3] == 1 and st[2] == 3 and st[1] >= 3 * W and (n == 1 or st[0] >= st[1] * (H - 1) + 3 * W)
+    if not ok:
+        frames = frames.contiguous()
+        st = frames.stride()
+    return frames, st[1], (st[0] if n > 1 else st[1] * H)
+
+
 class Context:
     def __init__(self, device=None):
         _require_gpu()
@@ -86,9 +100,10 @@ class Context:
 
     # ---- K1 -----------------------------------------------------------------------------------
     def gray(self, bgr):
+        bgr, pitch, fstride = _frame_layout(bgr)
         n, H, W = bgr.shape[0], bgr.shape[1], bgr.shape[2]
         out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_gray_u8(self._h, _ptr(bgr), n, H, W, W * 3, H * W * 3, _ptr(out), _stream_ptr()), "sv_gray_u8")
+        _native.check(_native.lib().sv_gray_u8(self._h, _ptr(bgr), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_gray_u8")
         return out
 
     def blur(self, gray, ksize):
@@ -105,10 +120,12 @@ class Context:
         return out
 
     def preprocess(self, frames):
-        """frames u8 [n,H,W,3] on device -> binary u8 [n,H,W] (preprocess_for_grid_detection)."""
+        """frames u8 [n,H,W,3] on device (rows may be padded, frames may have gaps) -> binary u8 [n,H,W]
+        (preprocess_for_grid_detection)."""
+        frames, pitch, fstride = _frame_layout(frames)
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
         out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
+        _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
         return out
 
     def despeckle(self, binary, out=None, packed=None):
@@ -152,9 +169,10 @@ class Context:
         return out
 
     def warp_cells(self, frames, minv_dev):
+        frames, pitch, fstride = _frame_layout(frames)
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
         out = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_warp_cells_u8(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(minv_dev), _ptr(out), _stream_ptr()),
+        _native.check(_native.lib().sv_warp_cells_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(minv_dev), _ptr(out), _stream_ptr()),
                       "sv_warp_cells_u8")
         return out
 
@@ -320,6 +338,7 @@ class Context:
     # ---- whole path ---------------------------------------------------------------------------
     def frames_to_digits(self, frames, minv_dev, out=None, keep_cells=False, glue=0):
         """frames u8 [n,H,W,3], minv_dev f64 [n,3,3] on device -> dict(logits [n,81,10], digits [n,81], conf [n,81])."""
+        frames, pitch, fstride = _frame_layout(frames)
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
         if out is None:
             out = {"logits": torch.empty((n, 81, 10), dtype=torch.float32, device=self.device),
@@ -328,7 +347,7 @@ class Context:
             if keep_cells:
                 out["cells"] = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device)
         cells = out.get("cells")
-        _native.check(_native.lib().sv_frames_to_digits(self._h, _ptr(frames), n, H, W, W * 3, H * W * 3, _ptr(minv_dev), int(glue),
+        _native.check(_native.lib().sv_frames_to_digits(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(minv_dev), int(glue),
                                                         _ptr(cells) if cells is not None else None, _ptr(out["logits"]), _ptr(out["digits"]),
                                                         _ptr(out["conf"]), _stream_ptr()), "sv_frames_to_digits")
         return out

@@ -531,3 +531,29 @@ def test_full_size_batch_properties(ctx, golden_dir):
         el, ed, ec = cnn_oracle.predict(sd, o.cells_to_input(cells)[:, None])
         assert np.abs(full["logits"][i].cpu().numpy() - el.numpy()).max() <= LOGIT_TOL
         assert (full["digits"][i].cpu().numpy() == ed.numpy()).all()
+
+
+@pytest.mark.parametrize("row_pad,frame_gap", [(64, 0), (20, 0), (7, 0), (64, 4096), (12, 100)])
+def test_padded_rows_and_frame_gaps(ctx, golden_dir, row_pad, frame_gap):
+    """Camera buffers are rarely dense: the C ABI takes a row pitch and a frame stride.  Frames embedded in a larger buffer with
+    `row_pad` bytes after every row and `frame_gap` bytes between frames (garbage in the padding) give the same binary, cells and
+    digits as the dense copy -- through the 4-byte-aligned marching K1 (pad 64), the tiled fallback (pads 20, 12) and the
+    unaligned-pitch path (pad 7)."""
+    import sudoku_vision_amd as sva
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    ctx.load_state_dict({k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS})
+    n, H, W = 3, 270, 480
+    dense, corners, _ = _frames(n, H, W, seed=row_pad + frame_gap)
+    pitch = 3 * W + row_pad
+    fstride = pitch * H + frame_gap
+    buf = torch.randint(0, 256, (n * fstride + 64,), dtype=torch.uint8, device="cuda")       # garbage everywhere first
+    view = torch.as_strided(buf, (n, H, W, 3), (fstride, pitch, 3, 1))
+    view.copy_(dense)
+    assert not view.is_contiguous()
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners))
+    assert torch.equal(ctx.preprocess(view), ctx.preprocess(dense))
+    assert torch.equal(ctx.gray(view), ctx.gray(dense))
+    assert torch.equal(ctx.warp_cells(view, minv), ctx.warp_cells(dense, minv))
+    a, b = ctx.frames_to_digits(view, minv), ctx.frames_to_digits(dense, minv)
+    assert torch.equal(a["digits"], b["digits"]) and torch.equal(a["logits"], b["logits"])
+    assert (ctx.preprocess(dense)[0].cpu().numpy() == o.preprocess_for_grid_detection(dense[0].cpu().numpy())).all()

@@ -9,7 +9,9 @@ classifies chunk i-1.  `glue` selects what sits between extract_cells and the mo
 A frame whose grid is not found gets found=False and digits 0 (the reference
 returns "Grid detection failed" for it, pipeline/run.py:268-272)."""
 import os
+import time
 from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
 
 import numpy as np
 import torch
@@ -146,3 +148,147 @@ def run_solver(grid):
     code, sol = host.solve_sudoku(grid)
     g = [[int(v) for v in row] for row in np.asarray(grid).reshape(9, 9)]
     return (True, [[int(v) for v in row] for row in sol]) if code == 1 else (False, g)
+
+
+# ---- the harness's own entry point (pipeline/run.py:36-66, 205-334), same result fields and error strings ------------------
+@dataclass
+class CellPrediction:
+    """pipeline/run.py:36-43"""
+    row: int
+    col: int
+    digit: int                      # 0 = empty, 1-9 = digit
+    confidence: float
+    is_original: bool = True        # True if read from the image, False if filled in by the solver
+
+
+@dataclass
+class PipelineResult:
+    """pipeline/run.py:46-66 (same fields; times in seconds)"""
+    success: bool
+    error: str = None
+    time_cv: float = 0.0
+    time_ml: float = 0.0
+    time_solver: float = 0.0
+    time_total: float = 0.0
+    original_image: np.ndarray = None
+    warped_grid: np.ndarray = None
+    cells: list = field(default_factory=list)
+    predictions: list = field(default_factory=list)
+    recognized_grid: list = field(default_factory=list)
+    solution: list = field(default_factory=list)
+    low_confidence_cells: list = field(default_factory=list)
+    constraint_violations: list = field(default_factory=list)
+
+
+def check_constraints(grid):
+    """The messages of pipeline/run.py:69-111 for a 9x9 grid: one entry per repeated value in a row, a column or a box
+    (0 = empty is ignored); a value seen three times in a unit yields two entries, each naming the previous occurrence."""
+    out = []
+    units = [("row", r, [(r, c) for c in range(9)]) for r in range(9)]
+    units += [("col", c, [(r, c) for r in range(9)]) for c in range(9)]
+    units += [("box", b, [(3 * (b // 3) + i, 3 * (b % 3) + j) for i in range(3) for j in range(3)]) for b in range(9)]
+    for kind, idx, members in units:
+        last = {}
+        for r, c in members:
+            v = grid[r][c]
+            if v <= 0:
+                continue
+            if v in last:
+                pr, pc = last[v]
+                if kind == "row":
+                    out.append(f"Row {idx + 1}: duplicate {v} at columns {pc + 1} and {c + 1}")
+                elif kind == "col":
+                    out.append(f"Column {idx + 1}: duplicate {v} at rows {pr + 1} and {r + 1}")
+                else:
+                    out.append(f"Box ({idx // 3 + 1},{idx % 3 + 1}): duplicate {v}")
+            last[v] = (r, c)
+    return out
+
+
+def run_pipeline(image_path, state_dict=None, ctx=None, debug=False, low_confidence=0.7):
+    """run_pipeline(image_path) of pipeline/run.py:205-334 on the MI355X path: JPEG -> frame in HBM (imgcodecs) -> K1 -> host
+    corner search -> K2 (warped 450x450 grid kept, as the reference keeps it) -> preprocess_cell + DigitCNN (K3) -> constraint
+    check -> in-process solver.  Same PipelineResult fields, same error strings, same partial results on failure."""
+    from . import imgcodecs
+    from .runtime import default_context
+    res = PipelineResult(success=False)
+    t_total = time.time()
+    ctx = ctx or default_context()
+    if state_dict is not None:
+        ctx.load_state_dict(state_dict)
+    frame = imgcodecs.imread(image_path, device=True, ctx=ctx)
+    if frame is None:
+        res.error = f"Failed to load image: {image_path}"
+        return res
+    res.original_image = frame.cpu().numpy()
+
+    t_cv = time.time()
+    try:
+        binary = ctx.preprocess(frame[None])[0].cpu().numpy()
+    except Exception as e:                                   # noqa: BLE001 -- the reference reports, it does not raise
+        res.error = f"Preprocessing failed: {e}"
+        return res
+    try:
+        corners = host.find_grid_corners(binary)
+        if corners is None:
+            res.error = "Grid detection failed: no quadrilateral found"
+            return res
+    except Exception as e:                                   # noqa: BLE001
+        res.error = f"Grid detection failed: {e}"
+        return res
+    try:
+        minv = ctx.minv_to_device(Context.corners_to_minv(corners[None].astype(np.float32)))
+        warped = ctx.warp_perspective(frame, minv[0], 450)
+        res.warped_grid = warped.cpu().numpy()
+    except Exception as e:                                   # noqa: BLE001
+        res.error = f"Perspective warp failed: {e}"
+        return res
+    try:
+        cells = ctx.extract_cells(warped, 28, 5, 5)          # cv/extract.py:13-56 defaults: 50-px cells, 10 % margin
+        res.cells = list(cells.cpu().numpy())
+        if len(res.cells) != 81:
+            res.error = f"Cell extraction failed: expected 81 cells, got {len(res.cells)}"
+            return res
+    except Exception as e:                                   # noqa: BLE001
+        res.error = f"Cell extraction failed: {e}"
+        return res
+    res.time_cv = time.time() - t_cv
+
+    t_ml = time.time()
+    try:
+        logits, digits, conf = ctx.cnn_forward(cells, want_digits=True, glue=Context.GLUE_RUNPY)
+        digits, conf = digits.cpu().numpy(), conf.cpu().numpy()
+        res.predictions = [CellPrediction(row=i // 9, col=i % 9, digit=int(digits[i]), confidence=float(conf[i])) for i in range(81)]
+        grid = [[int(digits[r * 9 + c]) for c in range(9)] for r in range(9)]
+        res.recognized_grid = grid
+        res.low_confidence_cells = [(p.row, p.col, p.confidence) for p in res.predictions if p.digit > 0 and p.confidence < low_confidence]
+    except Exception as e:                                   # noqa: BLE001
+        res.error = f"ML inference failed: {e}"
+        return res
+    res.time_ml = time.time() - t_ml
+
+    res.constraint_violations = check_constraints(grid)
+    if res.constraint_violations and debug:
+        print(f"Warning: {len(res.constraint_violations)} constraint violations detected")
+        for v in res.constraint_violations[:5]:
+            print(f"  - {v}")
+
+    t_solver = time.time()
+    try:
+        ok, solution = run_solver(grid)
+        if ok:
+            res.solution = solution
+            for p in res.predictions:
+                if p.digit == 0:
+                    p.digit = solution[p.row][p.col]
+                    p.is_original = False
+        else:
+            res.error = "Solver failed: puzzle may be invalid or have recognition errors"
+            res.solution = grid                              # the reference still returns the partial result
+    except Exception as e:                                   # noqa: BLE001
+        res.error = f"Solver error: {e}"
+        return res
+    res.time_solver = time.time() - t_solver
+    res.time_total = time.time() - t_total
+    res.success = ok
+    return res

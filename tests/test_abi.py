@@ -114,3 +114,20 @@ def test_winograd_stream_schedule():
                 assert (sc & 1) != (cc & 1) or sc == cc
                 staged = sc
         assert conv_done == ncell - 1
+
+
+def test_check_constraints_messages():
+    """The harness's constraint messages (pipeline/run.py:69-111): format and the 'previous occurrence' rule."""
+    from sudoku_vision_amd.pipeline import check_constraints
+    g = [[0] * 9 for _ in range(9)]
+    assert check_constraints(g) == []
+    g[0][1] = g[0][4] = g[0][8] = 7                 # three 7s in row 1 (boxes 1, 2, 3: no box clash)
+    g[3][2] = g[6][2] = 5                           # two 5s in column 3
+    g[4][4] = g[5][5] = 9                           # two 9s in the centre box only
+    assert check_constraints(g) == [
+        "Row 1: duplicate 7 at columns 2 and 5", "Row 1: duplicate 7 at columns 5 and 9",
+        "Column 3: duplicate 5 at rows 4 and 7",
+        "Box (2,2): duplicate 9"]
+    g2 = [[0] * 9 for _ in range(9)]
+    g2[0][0] = g2[1][1] = g2[2][2] = 4              # box (1,1) three times
+    assert check_constraints(g2) == ["Box (1,1): duplicate 4", "Box (1,1): duplicate 4"]

@@ -92,3 +92,41 @@ def test_imdecode_batch(ctx):
         assert (t.cpu().numpy() == pil_bgr(d)).all()
     with pytest.raises(sva._native.NativeError):
         ctx.imdecode_batch([same[0], b"\xff\xd8 this is not a jpeg"], threads=2)
+
+
+def test_run_pipeline_counterpart(ctx, golden_dir, tmp_path):
+    """pipeline/run.py:205-334's run_pipeline on the MI355X path: same result fields, same error strings."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.pipeline import PipelineResult, recognize_image, run_pipeline, run_solver, check_constraints
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    path = os.path.join(golden_dir, "sample_4.jpg")
+    res = run_pipeline(path, state_dict=sd, ctx=ctx)
+    assert isinstance(res, PipelineResult)
+    assert res.original_image.shape == (3648, 2736, 3) and res.warped_grid.shape == (450, 450, 3)
+    assert len(res.cells) == 81 and all(c.shape == (28, 28) and c.dtype == np.uint8 for c in res.cells)
+    assert len(res.predictions) == 81 and [(p.row, p.col) for p in res.predictions] == [(i // 9, i % 9) for i in range(81)]
+    # the staged cells (warp, then extract) are the fused kernel's cells; the grid is recognize_image's
+    ref = recognize_image(res.original_image, ctx=ctx)
+    assert res.recognized_grid == ref["grid"]
+    img = res.original_image
+    corners = sva.host.find_grid_corners(ctx.preprocess(torch.from_numpy(img).cuda()[None])[0].cpu().numpy())
+    assert (res.warped_grid == o.warp_perspective(img, corners.astype(np.float32))).all()
+    assert (np.stack(res.cells) == o.warp_cells(img, corners.astype(np.float32))).all()
+    assert res.constraint_violations == check_constraints(res.recognized_grid)
+    ok, sol = run_solver(res.recognized_grid)
+    assert res.success == ok and res.solution == sol
+    if ok:
+        assert res.error is None and all(p.digit == sol[p.row][p.col] for p in res.predictions)
+        assert all(p.is_original == (res.recognized_grid[p.row][p.col] != 0) for p in res.predictions)
+    else:
+        assert res.error == "Solver failed: puzzle may be invalid or have recognition errors" and res.solution == res.recognized_grid
+    assert all(0 <= r < 9 and 0 <= c < 9 and cf < 0.7 for r, c, cf in res.low_confidence_cells)
+    assert res.time_total >= res.time_cv > 0 and res.time_ml > 0
+    # error conventions
+    miss = run_pipeline(tmp_path / "missing.jpg", ctx=ctx)
+    assert not miss.success and miss.error == f"Failed to load image: {tmp_path / 'missing.jpg'}"
+    blank = tmp_path / "blank.jpg"
+    Image.fromarray(np.full((480, 640, 3), 200, np.uint8)).save(blank, "JPEG", quality=90)
+    nog = run_pipeline(blank, ctx=ctx)
+    assert not nog.success and nog.error == "Grid detection failed: no quadrilateral found" and nog.original_image.shape == (480, 640, 3)

@@ -107,11 +107,11 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lane_prev(float v)   // value held by lane-1
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_next(float v)   // value held by lane+1
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float gray_f32(float b, float g, float r)
 {
@@ -387,10 +387,10 @@ __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__
                 const int q = qs + i;                            // blurred row of this push (rows > H-1 repeat row H-1)
                 const u32x3 raw_cur = raw[ph % PF];
                 raw[ph % PF] = load_raw(q + 2 + PF < H + 2 ? q + 2 + PF : H + 1);   // row that push i + PF will consume
-                hw[ph % 6] = hrow(raw_cur);                      // h row q+2; rows q-2 .. q+1 sit in the 4 slots before it
-                f32x4_t nbf, nrw;
-                finish_row(hw[(ph + 2) % 6], hw[(ph + 3) % 6], hw[(ph + 4) % 6], hw[(ph + 5) % 6], hw[ph % 6], nbf, nrw);
-                if (q <= H - 1) { cur_bf = nbf; cur_rw = nrw; }   // (a select, not a branch: bottom REPLICATE pushes the last row again)
+                if (q <= H - 1) {                                // wave-uniform; bottom REPLICATE pushes the last blurred row again
+                    hw[ph % 6] = hrow(raw_cur);                  // h row q+2; rows q-2 .. q+1 sit in the 4 slots before it
+                    finish_row(hw[(ph + 2) % 6], hw[(ph + 3) % 6], hw[(ph + 4) % 6], hw[(ph + 5) % 6], hw[ph % 6], cur_bf, cur_rw);
+                }                                                // (no memory operation inside: the row loads stay in straight-line code)
                 if (i == 0) {
 #pragma unroll
                     for (int k = 0; k < NPH; k++) win[k] = cur_rw;   // top REPLICATE: rows above the first one read the first one

@@ -324,7 +324,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
     long ncell = B - c0;
     if (ncell > cells_per_wg) ncell = cells_per_wg;
     if (ncell <= 0) return;
-    const long ntiles = ncell * 49, NM = (ntiles + 15) / 16;
+    const int ntiles = (int)ncell * 49, NM = (ntiles + 15) / 16;   // tile arithmetic in 32 bits (a workgroup never owns 2^31 / 49 cells)
+    float *featw = feat + c0 * FEAT;                               // this workgroup's first cell
 
     float ureg[16][8];
     float bias2 = 0.f;
@@ -380,14 +381,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
             }
         }
     };
-    auto transform = [&](long m) {            // producers: V[m & 1] = B^T d B for the 16 tiles of M tile m
+    auto transform = [&](int m) {             // producers: V[m & 1] = B^T d B for the 16 tiles of M tile m
         float *Vs = v_base + (m & 1) * VSLOT;
         for (int it = ptid; it < 512; it += 256) {
             const int ic = it >> 4, tl = it & 15;
-            long T = 16 * m + tl;
+            int T = 16 * m + tl;
             if (T > ntiles - 1) T = ntiles - 1;
-            const long c = T / 49;
-            const int t = (int)(T - 49 * c), wy = t / 7, wx = t - 7 * wy;
+            const int c = T / 49;
+            const int t = T - 49 * c, wy = t / 7, wx = t - 7 * wy;
             const float *d = c1_base + (c & 1) * C1_CELL + ic * PLANE + (2 * wy) * 16 + 2 * wx;
             float tt[4][4];
 #pragma unroll
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
     if (!consumer) transform(0);
     __syncthreads();
 
-    for (long m = 0; m < NM; m++) {
+    for (int m = 0; m < NM; m++) {
         if (consumer) {
             const float *ap = v_base + (m & 1) * VSLOT + q * 16 + r16;
             f32x4 acc[16];
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
                     acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(xi * 32 + 4 * ks) * 16], ureg[xi][ks], acc[xi], 0, 0, 0);
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const long T = 16 * m + 4 * q + reg;
+                const int T = 16 * m + 4 * q + reg;
                 float s0[4], s1[4];
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
@@ -441,10 +442,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
                 const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
                 const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
                 const float pooled = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias2, 0.f);
-                if (T < ntiles) {
-                    const long c = T / 49;
-                    feat[(c0 + c) * FEAT + (T - 49 * c) * 64 + 16 * nt + r16] = pooled;
-                }
+                if (T < ntiles) featw[(unsigned)(T * 64 + 16 * nt + r16)] = pooled;   // (cell c, tile t) sits at c*3136 + t*64 = T*64
             }
         } else {
             if (m + 1 < NM) transform(m + 1);

@@ -327,15 +327,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
     const int ntiles = (int)ncell * 49, NM = (ntiles + 15) / 16;   // tile arithmetic in 32 bits (a workgroup never owns 2^31 / 49 cells)
     float *featw = feat + c0 * FEAT;                               // this workgroup's first cell
 
-    float ureg[16][8];
-    float bias2 = 0.f;
-    if (consumer) {
-#pragma unroll
-        for (int xi = 0; xi < 16; xi++)
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) ureg[xi][ks] = ureg_img[((nt * 16 + xi) * 8 + ks) * 64 + lane];
-        bias2 = b2[16 * nt + r16];
-    }
     for (int i = tid; i < 2 * IN_CELL + 2 * C1_CELL + 2 * VSLOT; i += 512) lds[i] = 0.f;
     __syncthreads();
 
@@ -349,13 +340,26 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
             in_s[(y + 1) * IN_W + x + 1] = v;
         }
     };
+    // conv1 + ReLU + 2x2 max: a producer thread owns one group of 4 output channels (og = ptid / 32, the same for every item
+    // and every cell, so its 36 weights + 4 biases stay in registers as {w, w} pairs) and walks the 196 pooled pixels in
+    // steps of 32.  The two halves of a wave read the same input patches (LDS broadcast).
+    const int og = ptid >> 5, pl = ptid & 31;
+    f32x2 wreg[4][9], breg[4];
+    auto conv1_load_weights = [&]() {
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const float bias = b1[og * 4 + o];
+            breg[o] = (f32x2){bias, bias};
+#pragma unroll
+            for (int t = 0; t < 9; t++) { const float w = w1[(og * 4 + o) * 9 + t]; wreg[o][t] = (f32x2){w, w}; }
+        }
+    };
     auto conv1 = [&](long c) {                // producers: in_s[c & 1] -> c1[c & 1]
         const float *in_s = in_base + (c & 1) * IN_CELL;
-        float *c1 = c1_base + (c & 1) * C1_CELL;
-        for (int it = ptid; it < 196 * 8; it += 256) {
-            const int og = it / 196, pp = it - og * 196, py = pp / 14, px = pp - py * 14;
-            // the 4x4 input patch as overlapping horizontal pairs: one v_pk_fma_f32 does the two outputs of a pooling-window
-            // row (this wave issues almost alone on its SIMD, where a packed FMA costs barely more than a plain one)
+        float *c1 = c1_base + (c & 1) * C1_CELL + og * 4 * PLANE;
+        for (int pp = pl; pp < 196; pp += 32) {
+            const int py = pp / 14, px = pp - py * 14;
+            // the 4x4 input patch as overlapping horizontal pairs: one v_pk_fma_f32 does the two outputs of a pooling-window row
             f32x2 pr[4][3];
             const float *src = in_s + (2 * py) * IN_W + 2 * px;
 #pragma unroll
@@ -365,25 +369,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
             float *dstp = c1 + (py + 1) * 16 + px + 1;
 #pragma unroll
             for (int o = 0; o < 4; o++) {
-                const int oc = og * 4 + o;
-                const float *w = w1 + oc * 9;
-                const float bias = b1[oc];
-                f32x2 a0 = {bias, bias}, a1 = {bias, bias};          // output rows dy = 0, 1; lanes = dx 0, 1
+                f32x2 a0 = breg[o], a1 = breg[o];                    // output rows dy = 0, 1; lanes = dx 0, 1
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++)
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++) {
-                        const f32x2 wv = {w[ky * 3 + kx], w[ky * 3 + kx]};
-                        a0 = __builtin_elementwise_fma(wv, pr[ky][kx], a0);
-                        a1 = __builtin_elementwise_fma(wv, pr[ky + 1][kx], a1);
+                        a0 = __builtin_elementwise_fma(wreg[o][ky * 3 + kx], pr[ky][kx], a0);
+                        a1 = __builtin_elementwise_fma(wreg[o][ky * 3 + kx], pr[ky + 1][kx], a1);
                     }
-                dstp[oc * PLANE] = fmaxf(fmaxf(fmaxf(a0[0], a0[1]), fmaxf(a1[0], a1[1])), 0.f);
+                dstp[o * PLANE] = fmaxf(fmaxf(fmaxf(a0[0], a0[1]), fmaxf(a1[0], a1[1])), 0.f);
             }
         }
     };
-    auto transform = [&](int m) {             // producers: V[m & 1] = B^T d B for the 16 tiles of M tile m
+    auto transform = [&](int m, int first, int last) {   // V[m & 1] = B^T d B for the 16 tiles of M tile m, items [first, last)
         float *Vs = v_base + (m & 1) * VSLOT;
-        for (int it = ptid; it < 512; it += 256) {
+        for (int it = first + ptid; it < last; it += 256) {
             const int ic = it >> 4, tl = it & 15;
             int T = 16 * m + tl;
             if (T > ntiles - 1) T = ntiles - 1;
@@ -407,50 +407,69 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
         }
     };
 
-    // prologue
-    long conv_done = ncell > 1 ? 1 : 0, staged = conv_done;
-    if (!consumer) { stage(0); if (ncell > 1) stage(1); }
-    __syncthreads();
-    if (!consumer) { conv1(0); if (ncell > 1) conv1(1); }
-    __syncthreads();
-    if (!consumer) transform(0);
-    __syncthreads();
-
-    for (int m = 0; m < NM; m++) {
-        if (consumer) {
-            const float *ap = v_base + (m & 1) * VSLOT + q * 16 + r16;
-            f32x4 acc[16];
-#pragma unroll
-            for (int xi = 0; xi < 16; xi++) acc[xi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // k-step outermost: consecutive MFMAs hit 16 different accumulators (a dependent 16x16x4 f32 MFMA needs 40
-            // cycles, an independent one issues every 32)
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++)
-#pragma unroll
-                for (int xi = 0; xi < 16; xi++)
-                    acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(xi * 32 + 4 * ks) * 16], ureg[xi][ks], acc[xi], 0, 0, 0);
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int T = 16 * m + 4 * q + reg;
-                float s0[4], s1[4];
-#pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const float m0 = acc[x][reg], m1 = acc[4 + x][reg], m2 = acc[8 + x][reg], m3 = acc[12 + x][reg];
-                    s0[x] = m0 + m1 + m2;
-                    s1[x] = m1 - m2 - m3;
-                }
-                const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
-                const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-                const float pooled = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias2, 0.f);
-                if (T < ntiles) featw[(unsigned)(T * 64 + 16 * nt + r16)] = pooled;   // (cell c, tile t) sits at c*3136 + t*64 = T*64
-            }
-        } else {
-            if (m + 1 < NM) transform(m + 1);
+    // The two roles run separate loops (one barrier per step in each, so the counts match): register liveness then stays
+    // within a role -- U (128 VGPRs) is never live in producer code, nor the conv1 weights in consumer code.
+    if (!consumer) {
+        conv1_load_weights();
+        long conv_done = ncell > 1 ? 1 : 0, staged = conv_done;
+        stage(0);
+        if (ncell > 1) stage(1);
+        __syncthreads();
+        conv1(0);
+        if (ncell > 1) conv1(1);
+        __syncthreads();
+        transform(0, 0, 512);
+        __syncthreads();
+        for (int m = 0; m < NM; m++) {
+            if (m + 1 < NM) transform(m + 1, 0, 256);
             const long cc = wstream_need(m, ncell);
             if (cc > conv_done) { conv1(cc); conv_done = cc; }
             const long sc = wstream_need(m + 1, ncell);
             if (sc > staged) { stage(sc); staged = sc; }
+            __syncthreads();
         }
+        return;
+    }
+
+    float ureg[16][8];
+#pragma unroll
+    for (int xi = 0; xi < 16; xi++)
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) ureg[xi][ks] = ureg_img[((nt * 16 + xi) * 8 + ks) * 64 + lane];
+    const float bias2 = b2[16 * nt + r16];
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    for (int m = 0; m < NM; m++) {
+        const float *ap = v_base + (m & 1) * VSLOT + q * 16 + r16;
+        f32x4 acc[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; xi++) acc[xi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // k-step outermost: consecutive MFMAs hit 16 different accumulators (a dependent 16x16x4 f32 MFMA needs 40
+        // cycles, an independent one issues every 32)
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+            for (int xi = 0; xi < 16; xi++)
+                acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(xi * 32 + 4 * ks) * 16], ureg[xi][ks], acc[xi], 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int T = 16 * m + 4 * q + reg;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const float m0 = acc[x][reg], m1 = acc[4 + x][reg], m2 = acc[8 + x][reg], m3 = acc[12 + x][reg];
+                s0[x] = m0 + m1 + m2;
+                s1[x] = m1 - m2 - m3;
+            }
+            const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+            const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+            const float pooled = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias2, 0.f);
+            if (T < ntiles) featw[(unsigned)(T * 64 + 16 * nt + r16)] = pooled;   // (cell c, tile t) sits at c*3136 + t*64 = T*64
+        }
+        // The MFMA stream above starves the producer waves (f32 MFMA and VALU share the SIMD's issue); what is left of the
+        // step is VALU-only, and two waves per SIMD issue VALU faster than one: take half of the next input transform.
+        if (m + 1 < NM) transform(m + 1, 256, 512);
         __syncthreads();
     }
 }

@@ -330,16 +330,37 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
     for (int i = tid; i < 2 * IN_CELL + 2 * C1_CELL + 2 * VSLOT; i += 512) lds[i] = 0.f;
     __syncthreads();
 
-    auto stage = [&](long c) {                // producers (256 threads): input of local cell c -> in_s[c & 1]
-        float *in_s = in_base + (c & 1) * IN_CELL;
-        for (int i = ptid; i < 784; i += 256) {
-            const int y = i / 28, x = i - y * 28;
-            float v;
-            if (U8IN) v = glue_norm(((const u8 *)xin)[(c0 + c) * 784 + i]);
-            else v = ((const float *)xin)[(c0 + c) * 784 + i];
-            in_s[(y + 1) * IN_W + x + 1] = v;
+    // Input of a cell -> in_s[c & 1], in two phases so that the global-load latency hides behind the step's other work:
+    // stage_load issues one load per value into registers (u8: the cell is 196 dwords, one per thread, 4 pixels of one row
+    // each; f32: 784 values, up to 4 per thread), stage_store converts and writes them into the zero-bordered LDS image.
+    unsigned sraw[4];
+    auto stage_load = [&](long c) {
+        if (U8IN) {
+            if (ptid < 196) sraw[0] = ((const unsigned *)((const u8 *)xin + (c0 + c) * 784))[ptid];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ptid + 256 * j < 784) sraw[j] = __float_as_uint(((const float *)xin)[(c0 + c) * 784 + ptid + 256 * j]);
         }
     };
+    auto stage_store = [&](long c) {
+        float *in_s = in_base + (c & 1) * IN_CELL;
+        if (U8IN) {
+            if (ptid < 196) {
+                const int y = ptid / 7, x = 4 * (ptid - 7 * y);
+                float *d = in_s + (y + 1) * IN_W + x + 1;
+#pragma unroll
+                for (int j = 0; j < 4; j++) d[j] = glue_norm((u8)(sraw[0] >> (8 * j)));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = ptid + 256 * j;
+                if (i < 784) { const int y = i / 28, x = i - y * 28; in_s[(y + 1) * IN_W + x + 1] = __uint_as_float(sraw[j]); }
+            }
+        }
+    };
+    auto stage = [&](long c) { stage_load(c); stage_store(c); };
     // conv1 + ReLU + 2x2 max: a producer thread owns one group of 4 output channels (og = ptid / 32, the same for every item
     // and every cell, so its 36 weights + 4 biases stay in registers as {w, w} pairs) and walks the 196 pooled pixels in
     // steps of 32.  The two halves of a wave read the same input patches (LDS broadcast).
@@ -421,11 +442,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
         transform(0, 0, 512);
         __syncthreads();
         for (int m = 0; m < NM; m++) {
+            const long sc = wstream_need(m + 1, ncell);
+            if (sc > staged) stage_load(sc);                      // lands while the transform and conv1 below run
             if (m + 1 < NM) transform(m + 1, 0, 256);
             const long cc = wstream_need(m, ncell);
             if (cc > conv_done) { conv1(cc); conv_done = cc; }
-            const long sc = wstream_need(m + 1, ncell);
-            if (sc > staged) { stage(sc); staged = sc; }
+            if (sc > staged) { stage_store(sc); staged = sc; }
             __syncthreads();
         }
         return;
@@ -740,7 +762,7 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
         x = ctx->cells2;
     }
     static const int conv_algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 2;     // cross-check aid: 0 = direct implicit GEMM (k_conv_features_pc), 2 = Winograd stream
-    if (conv_algo == 2) {
+    if (conv_algo == 2 && ((uintptr_t)x & 3) == 0) {             // the stream kernel reads 8-bit cells as dwords; a misaligned buffer takes the direct kernel
         long cpw = (B + ctx->num_cus - 1) / ctx->num_cus;
         if (cpw < 1) cpw = 1;
         const int grid_s = (int)((B + cpw - 1) / cpw);

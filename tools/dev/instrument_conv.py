@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development aid: patches cycle-counter stamps into k_conv_features_wstream (a scratch copy of csrc/k3_cnn.hip is
 written in place -- restore with `git checkout` afterwards) so that tools/dev/trace_conv.py can print a per-step timeline
-of one workgroup: consumer wave 0 (GEMM / output transform / help / barrier wait) and producer wave 4."""
+of one workgroup: consumer wave 0 (GEMM / output transform / help / barrier wait) and producer wave 4
+(transform / conv1 + input store / barrier wait)."""
 import os
 p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "sudoku-vision_amd", "csrc", "k3_cnn.hip")
 s = open(p).read()
@@ -21,29 +22,39 @@ def rep(old, new):
     k = k.replace(old, new, 1)
 
 
-rep('''        if (consumer) {
-            const float *ap = v_base + (m & 1) * VSLOT + q * 16 + r16;''', '''        TR(0);
-        if (consumer) {
-            const float *ap = v_base + (m & 1) * VSLOT + q * 16 + r16;''')
+rep('''        for (int m = 0; m < NM; m++) {
+            // conv1 of the next cell is spread''', '''        for (int m = 0; m < NM; m++) {
+            TR(0);
+            // conv1 of the next cell is spread''')
+rep('''            if (m + 1 < NM) transform(m + 1, 0, 256);
+            if (r > 0) {''', '''            if (m + 1 < NM) transform(m + 1, 0, 256);
+            TR(1);
+            if (r > 0) {''')
+rep('''                    conv_round = 0;
+                }
+            }
+            __syncthreads();''', '''                    conv_round = 0;
+                }
+            }
+            TR(2); TR(3);
+            __syncthreads();
+            TR(4);''')
+rep('''    for (int m = 0; m < NM; m++) {
+        const float *ap = v_base + (m & 1) * VSLOT + q * 16 + r16;''', '''    for (int m = 0; m < NM; m++) {
+        TR(0);
+        const float *ap = v_base + (m & 1) * VSLOT + q * 16 + r16;''')
 rep('''#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int T = 16 * m + 4 * q + reg;''', '''            TR(1);
+        for (int reg = 0; reg < 4; reg++) {
+            const int T = 16 * m + 4 * q + reg;''', '''        TR(1);
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int T = 16 * m + 4 * q + reg;''')
-rep('''            if (m + 1 < NM) transform(m + 1, 256, 512);''', '''            TR(2);
-            if (m + 1 < NM) transform(m + 1, 256, 512);''')
-rep('''            if (m + 1 < NM) transform(m + 1, 0, 256);''', '''            if (m + 1 < NM) transform(m + 1, 0, 256);
-            TR(1); TR(2);''')
-rep('''        }
-        __syncthreads();
-    }
-}''', '''        }
+        for (int reg = 0; reg < 4; reg++) {
+            const int T = 16 * m + 4 * q + reg;''')
+rep('''        if (m + 1 < NM) transform(m + 1, 256, 512);
+        __syncthreads();''', '''        TR(2);
+        if (m + 1 < NM) transform(m + 1, 256, 512);
         TR(3);
         __syncthreads();
-        TR(4);
-    }
-}''')
+        TR(4);''')
 s = s[:a] + k + s[b:]
 open(p, 'w').write(s)
 print("instrumented", p)

@@ -23,19 +23,15 @@ def rep(old, new):
 
 
 rep('''        for (int m = 0; m < NM; m++) {
-            // conv1 of the next cell is spread''', '''        for (int m = 0; m < NM; m++) {
+            const long sc = wstream_need(m + 1, ncell);''', '''        for (int m = 0; m < NM; m++) {
             TR(0);
-            // conv1 of the next cell is spread''')
+            const long sc = wstream_need(m + 1, ncell);''')
 rep('''            if (m + 1 < NM) transform(m + 1, 0, 256);
-            if (r > 0) {''', '''            if (m + 1 < NM) transform(m + 1, 0, 256);
+            const long cc = wstream_need(m, ncell);''', '''            if (m + 1 < NM) transform(m + 1, 0, 256);
             TR(1);
-            if (r > 0) {''')
-rep('''                    conv_round = 0;
-                }
-            }
-            __syncthreads();''', '''                    conv_round = 0;
-                }
-            }
+            const long cc = wstream_need(m, ncell);''')
+rep('''            if (sc > staged) { stage_store(sc); staged = sc; }
+            __syncthreads();''', '''            if (sc > staged) { stage_store(sc); staged = sc; }
             TR(2); TR(3);
             __syncthreads();
             TR(4);''')

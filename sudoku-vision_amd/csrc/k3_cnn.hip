@@ -593,8 +593,8 @@ __global__ __launch_bounds__(512) void k_fc_head_frame(const float *__restrict__
                                                        const float *__restrict__ b2, float *__restrict__ logits,
                                                        u8 *__restrict__ digits, float *__restrict__ conf)
 {
-    constexpr int CELLS = 81, ROWS = 96, CH = 2;                      // cells per workgroup, padded rows, 16-wide chunks per stage
-    __shared__ __attribute__((aligned(16))) f32x4 wt[2][CH * 8 * 64]; // 2 x 16 KB weight stages
+    constexpr int CELLS = 81, ROWS = 96, CH = 4, WPT = CH * 8 * 64 / 512;   // WPT float4 of weights per thread per stage                      // cells per workgroup, padded rows, 16-wide chunks per stage
+    __shared__ __attribute__((aligned(16))) f32x4 wt[2][CH * 8 * 64]; // 2 x 32 KB weight stages
     __shared__ float hs[ROWS][129];
     __shared__ float w2s[10][128];
     __shared__ float lg[ROWS][12];
@@ -618,12 +618,14 @@ __global__ __launch_bounds__(512) void k_fc_head_frame(const float *__restrict__
 #pragma unroll
     for (int t = 0; t < 8; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int NSTAGE = 196 / CH;                                  // 98 stages of 1024 float4 = 2 per thread
-    f32x4 wreg[2], areg[CH];
-    wreg[0] = wp[tid]; wreg[1] = wp[512 + tid];
+    constexpr int NSTAGE = 196 / CH;                                  // 49 stages of 2048 float4 = 4 per thread
+    f32x4 wreg[WPT], areg[CH];
+#pragma unroll
+    for (int j = 0; j < WPT; j++) wreg[j] = wp[512 * j + tid];
 #pragma unroll
     for (int c = 0; c < CH; c++) areg[c] = ap[c * 4];
-    wt[0][tid] = wreg[0]; wt[0][512 + tid] = wreg[1];
+#pragma unroll
+    for (int j = 0; j < WPT; j++) wt[0][512 * j + tid] = wreg[j];
     __syncthreads();
 
     for (int st = 0; st < NSTAGE; st++) {
@@ -632,8 +634,8 @@ __global__ __launch_bounds__(512) void k_fc_head_frame(const float *__restrict__
 #pragma unroll
         for (int c = 0; c < CH; c++) a[c] = areg[c];
         if (st + 1 < NSTAGE) {                                        // next stage: global -> registers while this one computes
-            wreg[0] = wp[(long)(st + 1) * 1024 + tid];
-            wreg[1] = wp[(long)(st + 1) * 1024 + 512 + tid];
+#pragma unroll
+            for (int j = 0; j < WPT; j++) wreg[j] = wp[(long)(st + 1) * (CH * 8 * 64) + 512 * j + tid];
 #pragma unroll
             for (int c = 0; c < CH; c++) areg[c] = ap[((st + 1) * CH + c) * 4];
         }
@@ -657,7 +659,10 @@ __global__ __launch_bounds__(512) void k_fc_head_frame(const float *__restrict__
                     for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][e], b[t][e], acc[t], 0, 0, 0);
             }
         }
-        if (st + 1 < NSTAGE) { wt[cur ^ 1][tid] = wreg[0]; wt[cur ^ 1][512 + tid] = wreg[1]; }
+        if (st + 1 < NSTAGE) {
+#pragma unroll
+            for (int j = 0; j < WPT; j++) wt[cur ^ 1][512 * j + tid] = wreg[j];
+        }
         __syncthreads();
     }
 

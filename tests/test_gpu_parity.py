@@ -128,7 +128,15 @@ def test_cnn_golden_fixtures(ctx, golden_dir):
 def test_cnn_u8_cells_entry(ctx):
     sd = cnn_oracle.random_state_dict(3)
     cells = np.random.RandomState(8).randint(0, 256, (100, 28, 28)).astype(np.uint8)
-    _check_cnn(ctx, sd, cells)
+    logits, _ = _check_cnn(ctx, sd, cells)
+    # a cell buffer that is not 4-byte aligned (the stream kernel reads cells as dwords: such a buffer takes the direct kernel)
+    buf = torch.zeros(100 * 784 + 8, dtype=torch.uint8, device="cuda")
+    for off in (1, 2, 3):
+        view = buf[off:off + 100 * 784].view(100, 28, 28)
+        view.copy_(torch.from_numpy(cells))
+        assert view.data_ptr() % 4 == off
+        got = ctx.cnn_forward(view)
+        assert (got - logits).abs().max().item() <= 2e-5
 
 
 def test_digitcnn_module_dropin(ctx, golden_dir):

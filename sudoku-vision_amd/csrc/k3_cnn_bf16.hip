@@ -55,13 +55,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_features_bf16(const u8 *__restr
     __syncthreads();
 
     const long npairs = (B + 1) / 2;
-    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
-        for (int i = tid; i < 2 * 784; i += 256) {
-            const int cl = i / 784, p = i - cl * 784, y = p / 28, x = p - y * 28;
-            long cg = pair * 2 + cl;
-            if (cg >= B) cg = B - 1;
-            in_s[cl * IN_CELL + (y + 1) * IN_W + x + 1] = glue_norm(cells[cg * 784 + p]);
+    // Input staging in two phases: the 2 x 196 dwords of the NEXT pair of cells are loaded into registers (one or two per
+    // thread) right after the current pair's have been written to LDS, so the load latency hides behind conv1 and conv2.
+    unsigned sraw[2] = {0, 0};
+    auto stage_load = [&](long pair) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int d = tid + 256 * k;
+            if (d < 392) {
+                const int cl = d >= 196 ? 1 : 0;
+                long cg = pair * 2 + cl;
+                if (cg >= B) cg = B - 1;
+                sraw[k] = ((const unsigned *)(cells + cg * 784))[d - 196 * cl];
+            }
         }
+    };
+    if ((long)blockIdx.x < npairs) stage_load(blockIdx.x);
+    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int d = tid + 256 * k;
+            if (d < 392) {
+                const int cl = d >= 196 ? 1 : 0, w = d - 196 * cl, y = w / 7, x = 4 * (w - 7 * y);
+                float *dst = in_s + cl * IN_CELL + (y + 1) * IN_W + x + 1;
+#pragma unroll
+                for (int j = 0; j < 4; j++) dst[j] = glue_norm((u8)(sraw[k] >> (8 * j)));
+            }
+        }
+        if (pair + gridDim.x < npairs) stage_load(pair + gridDim.x);
         __syncthreads();
 
         // conv1 + ReLU + pool (f32), output rounded to bf16, channel-last: wave w owns channels 8w..8w+7 = one 16-B store
@@ -202,6 +223,7 @@ int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8
     const sv_weights &w = ctx->w;
     const long npairs = (B + 1) / 2;
     const int grid = (int)(npairs < 2L * ctx->num_cus ? npairs : 2L * ctx->num_cus);
+    if ((uintptr_t)cells & 3) return sv_fail(SV_ERR_UNSUPPORTED, "bf16 configuration: the 8-bit cell buffer must be 4-byte aligned (the kernel reads cells as dwords)");
     {
         sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
         hipLaunchKernelGGL(k_conv_features_bf16, dim3(grid), dim3(256), 0, s, cells, B, w.conv1_w, w.conv1_b, (const uint4 *)w.conv2_bf16, w.conv2_b,

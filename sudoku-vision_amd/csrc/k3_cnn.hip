@@ -11,9 +11,10 @@
 //        144 VGPRs for the life of the kernel.  The 16x16 accumulator holds the 4 positions of a
 //        pooling window in the 4 registers of one lane, so bias + ReLU + max-pool are 3 v_max and
 //        never leave the lane.  Output: features [cell][window 49][oc 64] f32.
-//   k_fc_head       : fc1 (3136->128) on the same MFMA with cells as M (explicit two-deep register pipeline
-//        for the weight/feature loads), + ReLU, fc2 (128->10), argmax (pipeline/run.py:142) and
-//        softmax[argmax] (run.py:141-143).
+//   k_fc_head_frame : fc1 (3136->128) on the same MFMA with cells as M, one workgroup per 81 cells, weights staged
+//        through double-buffered LDS; + ReLU, fc2 (128->10), argmax (pipeline/run.py:142) and softmax[argmax]
+//        (run.py:141-143).  k_fc_head: the same for small batches (16 cells per wave, weights streamed per wave).
+//   k_softmax_topk, k_preprocess_cells: the run_v2 top-k epilogue and run.py's preprocess_cell (scope rows N3, N1).
 //
 // Weight images are packed on the host by sv_load_weights_f32 (sv_api.cpp) into exactly the
 // per-lane register order the kernels load.

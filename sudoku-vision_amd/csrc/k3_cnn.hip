@@ -497,6 +497,256 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_conv_features_wsplit (experimental, SV_CONV_ALGO=3; measured 0.83 ms against the default's 0.81 ms): the Winograd stream
+// with its 16 GEMMs on the bf16 matrix pipe at f32 accuracy.
+// On gfx950 an f32 MFMA runs at the VALU's rate and blocks the SIMD's VALU issue while it runs (profiles/
+// r01_ubench_mfma_valu_coexec.txt); v_mfma_f32_16x16x32_bf16 does 8x the work per cycle and co-issues with VALU work.  Each
+// f32 operand is therefore split, without error, into three bf16 parts (x = h + m + l, each the next 8 mantissa bits, by
+// truncation: one v_and + one exact v_sub per part), and a product a*b becomes the six partial products
+// ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm accumulated in f32 -- what is dropped (am*bl, al*bm, al*bl) is below 2^-23 of
+// the product, i.e. below f32's own rounding.  U is split once on the host (sv_load_weights_f32), V when the input transform
+// writes it.  6 MFMAs of K = 32 replace 8 of K = 4: 96 matrix-pipe cycles per (M tile, N tile, xi) instead of 256.
+//
+// All 8 waves do everything (no producer/consumer split; the 96-register B image of a wave is (N tile nt, half of the xi)):
+//   phase A  every thread: one (channel, tile) item of V = B^T d B for M tile m, split and stored as bf16 [part][xi][tile][ic];
+//            waves 0-3 first finish M tile m-1: add the other half's partial output transform, bias, ReLU, pool, store
+//   barrier
+//   phase B  waves 0-3: 48 MFMAs (their 8 xi), partial output transform, then their conv1 share;
+//            waves 4-7: conv1 share first, then 48 MFMAs, partial output transform -> LDS
+//            (waves w and w+4 share a SIMD, so one's MFMAs run beside the other's VALU work)
+//   barrier
+// conv1: wave = 4-channel group (weights wave-uniform: scalar registers), lanes = pooled pixels, spread over the 3-4 steps in
+// which its plane buffer is free (wsplit_conv1_rounds); input staging in two phases as in k_conv_features_wstream.
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ inline int wsplit_conv1_rounds(long m, long tc, int done, int total)
+{
+    if (16 * m + 15 < 49 * (tc - 2) + 48) return 0;          // M tile m (transformed in this step's phase A) still short of cell tc-2's last tile
+    const long left = (49 * tc) / 16 - m;                      // steps m .. F-1, F = first M tile that touches cell tc
+    const int remaining = total - done;
+    return left <= 1 ? remaining : (int)((remaining + left - 1) / left);
+}
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <bool U8IN>
+__global__ __launch_bounds__(512, 2) void k_conv_features_wsplit(const void *__restrict__ xin, long B, long cells_per_wg,
+                                                                 const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                 const uint4 *__restrict__ usplit, const float *__restrict__ b2,
+                                                                 float *__restrict__ feat)
+{
+    constexpr int VROW = 80;                  // bytes per (xi, tile): 32 bf16 channels + 16 B of bank skew
+    constexpr int VPLANE = 16 * VROW;         // one xi: 16 tiles
+    constexpr int VPART = 16 * VPLANE;        // one bf16 part: 16 xi
+    __shared__ __attribute__((aligned(16))) float lds[2 * IN_CELL + 2 * C1_CELL];
+    __shared__ __attribute__((aligned(16))) unsigned char v3[3 * VPART];
+    __shared__ float ypart[4][16][64];        // partial output transforms of waves 4-7: [N tile][4 tiles x 4 values][lane]
+    __shared__ __attribute__((aligned(16))) float w1s[32][12];   // conv1 weights [0..8] and bias [9] (broadcast ds_reads; wave-uniform rows)
+    float *in_base = lds, *c1_base = lds + 2 * IN_CELL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 3, xh = wave >> 2;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    const long c0 = (long)blockIdx.x * cells_per_wg;
+    long ncell = B - c0;
+    if (ncell > cells_per_wg) ncell = cells_per_wg;
+    if (ncell <= 0) return;
+    const int ntiles = (int)ncell * 49, NM = (ntiles + 15) / 16;
+    float *featw = feat + c0 * FEAT;
+
+    uint4 breg[8][3];                         // [xi within this wave's half][part]: B[k = 8q + j][col r16] of U[xi], oc = 16nt + r16
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) breg[j][p] = usplit[((nt * 16 + 8 * xh + j) * 3 + p) * 64 + lane];
+    const float bias2 = b2[16 * nt + r16];
+    for (int i = tid; i < 2 * IN_CELL + 2 * C1_CELL; i += 512) lds[i] = 0.f;
+    for (int i = tid; i < 3 * VPART / 4; i += 512) ((unsigned *)v3)[i] = 0;
+    for (int i = tid; i < 320; i += 512) {
+        const int oc = i / 10, t = i - 10 * oc;
+        const float w = t < 9 ? w1[oc * 9 + t] : b1[oc];
+        w1s[oc][t] = w;
+    }
+    __syncthreads();
+
+    unsigned sraw[2];
+    auto stage_load = [&](long c) {
+        if (U8IN) {
+            if (tid < 196) sraw[0] = ((const unsigned *)((const u8 *)xin + (c0 + c) * 784))[tid];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (tid + 512 * j < 784) sraw[j] = __float_as_uint(((const float *)xin)[(c0 + c) * 784 + tid + 512 * j]);
+        }
+    };
+    auto stage_store = [&](long c) {
+        float *in_s = in_base + (c & 1) * IN_CELL;
+        if (U8IN) {
+            if (tid < 196) {
+                const int y = tid / 7, x = 4 * (tid - 7 * y);
+                float *d = in_s + (y + 1) * IN_W + x + 1;
+#pragma unroll
+                for (int j = 0; j < 4; j++) d[j] = glue_norm((u8)(sraw[0] >> (8 * j)));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int i = tid + 512 * j;
+                if (i < 784) { const int y = i / 28, x = i - y * 28; in_s[(y + 1) * IN_W + x + 1] = __uint_as_float(sraw[j]); }
+            }
+        }
+    };
+    constexpr int C1_ROUNDS = 4;              // 196 pooled pixels in rounds of 64 lanes; the wave is the 4-channel group
+    auto conv1 = [&](long c, int r0, int r1) {
+        const float *in_s = in_base + (c & 1) * IN_CELL;
+        float *c1 = c1_base + (c & 1) * C1_CELL + wave * 4 * PLANE;
+        for (int pp = lane + 64 * r0; pp < 196 && pp < 64 * r1; pp += 64) {
+            const int py = pp / 14, px = pp - py * 14;
+            // plain v_fma_f32 here, not v_pk_fma_f32: a packed f32 op issued beside the other wave's MFMAs costs ~20 cycles more
+            float pt[4][4];
+            const float *src = in_s + (2 * py) * IN_W + 2 * px;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) pt[i][j] = src[i * IN_W + j];
+            float *dstp = c1 + (py + 1) * 16 + px + 1;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const float *w = w1s[wave * 4 + o];
+                float a00 = w[9], a01 = w[9], a10 = w[9], a11 = w[9];
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const float wv = w[ky * 3 + kx];
+                        a00 = __builtin_fmaf(wv, pt[ky][kx], a00);
+                        a01 = __builtin_fmaf(wv, pt[ky][kx + 1], a01);
+                        a10 = __builtin_fmaf(wv, pt[ky + 1][kx], a10);
+                        a11 = __builtin_fmaf(wv, pt[ky + 1][kx + 1], a11);
+                    }
+                dstp[o * PLANE] = fmaxf(fmaxf(fmaxf(a00, a01), fmaxf(a10, a11)), 0.f);
+            }
+        }
+    };
+    // one (channel, tile) item of V = B^T d B for M tile m, each value split into three bf16 parts
+    auto transform = [&](int m) {
+        const int ic = tid >> 4, tl = tid & 15;
+        int T = 16 * m + tl;
+        if (T > ntiles - 1) T = ntiles - 1;
+        const int c = T / 49;
+        const int t = T - 49 * c, wy = t / 7, wx = t - 7 * wy;
+        const float *d = c1_base + (c & 1) * C1_CELL + ic * PLANE + (2 * wy) * 16 + 2 * wx;
+        float tt[4][4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const float d0 = d[x], d1 = d[16 + x], d2 = d[32 + x], d3 = d[48 + x];
+            tt[0][x] = d0 - d2; tt[1][x] = d1 + d2; tt[2][x] = d2 - d1; tt[3][x] = d1 - d3;
+        }
+        unsigned char *vp = v3 + tl * VROW + ic * 2;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const float v4[4] = {tt[y][0] - tt[y][2], tt[y][1] + tt[y][2], tt[y][2] - tt[y][1], tt[y][1] - tt[y][3]};
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const float v = v4[x];
+                const unsigned uh = __float_as_uint(v) & 0xffff0000u;
+                const float r = v - __uint_as_float(uh);                       // exact
+                const unsigned um = __float_as_uint(r) & 0xffff0000u;
+                const float r2 = r - __uint_as_float(um);                      // exact; its top 16 bits are the third part
+                unsigned char *o = vp + (y * 4 + x) * VPLANE;
+                *(unsigned short *)o = (unsigned short)(uh >> 16);
+                *(unsigned short *)(o + VPART) = (unsigned short)(um >> 16);
+                *(unsigned short *)(o + 2 * VPART) = (unsigned short)(__float_as_uint(r2) >> 16);
+            }
+        }
+    };
+
+    // prologue: cells 0 and 1 convolved, cell 2 staged
+    long conv_done = ncell > 1 ? 1 : 0;
+    int conv_round = 0;
+    stage_load(0); stage_store(0);
+    __syncthreads();
+    conv1(0, 0, C1_ROUNDS);
+    if (ncell > 1) { stage_load(1); stage_store(1); }
+    __syncthreads();
+    if (ncell > 1) conv1(1, 0, C1_ROUNDS);
+    if (ncell > 2) { stage_load(2); stage_store(2); }
+    __syncthreads();
+
+    float p0[4][4];                           // waves 0-3: this wave's partial output transform, [tile reg][y00, y01, y10, y11]
+    auto finish = [&](int m) {                // waves 0-3: M tile m's outputs = own partial + the other half's (in LDS)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int T = 16 * m + 4 * q + reg;
+            const float y00 = p0[reg][0] + ypart[nt][reg * 4 + 0][lane], y01 = p0[reg][1] + ypart[nt][reg * 4 + 1][lane];
+            const float y10 = p0[reg][2] + ypart[nt][reg * 4 + 2][lane], y11 = p0[reg][3] + ypart[nt][reg * 4 + 3][lane];
+            const float pooled = fmaxf(fmaxf(fmaxf(y00, y01), fmaxf(y10, y11)) + bias2, 0.f);
+            if (T < ntiles) featw[(unsigned)(T * 64 + 16 * nt + r16)] = pooled;
+        }
+    };
+
+    for (int m = 0; m < NM; m++) {
+        // ---- phase A
+        if (xh == 0 && m > 0) finish(m - 1);
+        transform(m);
+        __syncthreads();
+        // ---- phase B
+        const long tc = conv_done + 1;
+        const int rounds = tc < ncell ? wsplit_conv1_rounds(m, tc, conv_round, C1_ROUNDS) : 0;
+        const bool completes = rounds > 0 && conv_round + rounds == C1_ROUNDS;
+        if (completes && tc + 1 < ncell) stage_load(tc + 1);
+        if (xh == 1 && rounds > 0) conv1(tc, conv_round, conv_round + rounds);
+
+        f32x4 acc[8];
+        {
+            const unsigned char *ap = v3 + r16 * VROW + q * 16;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned char *a = ap + (8 * xh + j) * VPLANE;
+                const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *(const uint4 *)a);
+                const bf16x8_t am = __builtin_bit_cast(bf16x8_t, *(const uint4 *)(a + VPART));
+                const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *(const uint4 *)(a + 2 * VPART));
+                const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, breg[j][0]), bm = __builtin_bit_cast(bf16x8_t, breg[j][1]),
+                               bl = __builtin_bit_cast(bf16x8_t, breg[j][2]);
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};                               // smallest terms first
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, s, 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, s, 0, 0, 0);
+            }
+        }
+        // partial output transform over this wave's two rows of the 4x4 xi grid (xi = 4x + y, x in {2xh, 2xh+1}):
+        // r[x][0] = M[x][0] + M[x][1] + M[x][2], r[x][1] = M[x][1] - M[x][2] - M[x][3];
+        // Y[0][b] = r[0][b] + r[1][b] + r[2][b], Y[1][b] = r[1][b] - r[2][b] - r[3][b]
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const float ra0 = acc[0][reg] + acc[1][reg] + acc[2][reg], ra1 = acc[1][reg] - acc[2][reg] - acc[3][reg];   // first row of the half
+            const float rb0 = acc[4][reg] + acc[5][reg] + acc[6][reg], rb1 = acc[5][reg] - acc[6][reg] - acc[7][reg];   // second row
+            if (xh == 0) {                    // rows x = 0, 1: Y[0][b] += r0 + r1, Y[1][b] += r1
+                p0[reg][0] = ra0 + rb0; p0[reg][1] = ra1 + rb1; p0[reg][2] = rb0; p0[reg][3] = rb1;
+            } else {                          // rows x = 2, 3: Y[0][b] += r2, Y[1][b] += -r2 - r3
+                ypart[nt][reg * 4 + 0][lane] = ra0; ypart[nt][reg * 4 + 1][lane] = ra1;
+                ypart[nt][reg * 4 + 2][lane] = -ra0 - rb0; ypart[nt][reg * 4 + 3][lane] = -ra1 - rb1;
+            }
+        }
+        if (xh == 0 && rounds > 0) conv1(tc, conv_round, conv_round + rounds);
+        if (rounds > 0) {
+            conv_round += rounds;
+            if (completes) {
+                if (tc + 1 < ncell) stage_store(tc + 1);
+                conv_done = tc;
+                conv_round = 0;
+            }
+        }
+        __syncthreads();
+    }
+    if (xh == 0) finish(NM - 1);
+}
+
 // 64 cells per workgroup, 16 per wave; K = 3136 in 196 chunks of 16.
 __global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat, long B, const float *__restrict__ w1reg,
                                                  const float *__restrict__ b1, const float *__restrict__ w2,
@@ -767,8 +1017,19 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
         if (rc) return rc;
         x = ctx->cells2;
     }
-    static const int conv_algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 2;     // cross-check aid: 0 = direct implicit GEMM (k_conv_features_pc), 2 = Winograd stream
-    if (conv_algo == 2 && ((uintptr_t)x & 3) == 0) {             // the stream kernel reads 8-bit cells as dwords; a misaligned buffer takes the direct kernel
+    // cross-check aid: 0 = direct implicit GEMM (k_conv_features_pc), 2 = Winograd stream on f32 MFMA (default), 3 = Winograd stream on
+    // bf16 MFMA with three-way operand splitting (k_conv_features_wsplit)
+    static const int conv_algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 2;
+    if (conv_algo == 3 && ((uintptr_t)x & 3) == 0) {
+        long cpw = (B + ctx->num_cus - 1) / ctx->num_cus;
+        if (cpw < 1) cpw = 1;
+        const int grid_s = (int)((B + cpw - 1) / cpw);
+        sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
+        if (x_is_u8)
+            hipLaunchKernelGGL(k_conv_features_wsplit<true>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, (const uint4 *)w.conv2_wsplit, w.conv2_b, ctx->features);
+        else
+            hipLaunchKernelGGL(k_conv_features_wsplit<false>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, (const uint4 *)w.conv2_wsplit, w.conv2_b, ctx->features);
+    } else if (conv_algo == 2 && ((uintptr_t)x & 3) == 0) {             // the stream kernel reads 8-bit cells as dwords; a misaligned buffer takes the direct kernel
         long cpw = (B + ctx->num_cus - 1) / ctx->num_cus;
         if (cpw < 1) cpw = 1;
         const int grid_s = (int)((B + cpw - 1) / cpw);

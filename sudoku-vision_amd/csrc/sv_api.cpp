@@ -46,6 +46,8 @@ static void free_weights(sv_weights &w)
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    if (w.conv2_wsplit) (void)hipFree(w.conv2_wsplit);
+    w.conv2_wsplit = nullptr;
     if (w.conv2_bf16) (void)hipFree(w.conv2_bf16);
     if (w.fc1_bf16) (void)hipFree(w.fc1_bf16);
     w.conv2_bf16 = w.fc1_bf16 = nullptr;
@@ -180,6 +182,9 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
                 }
     // Winograd F(2x2,3x3) weights U = G g G^T (computed in double), as [nt][xi][ks][lane]: oc = 16nt + (lane&15), ic = 4ks + (lane>>4)
     std::vector<float> wino((size_t)4 * 16 * 8 * 64);
+    // the same U split without error into three bf16 parts (each the next 8 mantissa bits, by truncation) for
+    // k_conv_features_wsplit: [nt][xi][part][lane][j], oc = 16nt + (lane&15), ic = 8*(lane>>4) + j
+    std::vector<uint16_t> wsplit((size_t)4 * 16 * 3 * 64 * 8);
     {
         const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         for (int oc = 0; oc < 64; oc++)
@@ -191,7 +196,20 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
                 for (int i = 0; i < 4; i++)
                     for (int j = 0; j < 4; j++) U[i][j] = Gg[i][0] * G[j][0] + Gg[i][1] * G[j][1] + Gg[i][2] * G[j][2];
                 const int nt = oc >> 4, lane = (oc & 15) + 16 * (ic & 3), ks = ic >> 2;
-                for (int xi = 0; xi < 16; xi++) wino[(((size_t)nt * 16 + xi) * 8 + ks) * 64 + lane] = (float)U[xi >> 2][xi & 3];
+                for (int xi = 0; xi < 16; xi++) {
+                    const float u = (float)U[xi >> 2][xi & 3];
+                    wino[(((size_t)nt * 16 + xi) * 8 + ks) * 64 + lane] = u;
+                    float rest = u;
+                    for (int part = 0; part < 3; part++) {
+                        uint32_t bits;
+                        memcpy(&bits, &rest, 4);
+                        bits &= 0xffff0000u;
+                        float piece;
+                        memcpy(&piece, &bits, 4);
+                        rest -= piece;                                        // exact
+                        wsplit[((((size_t)nt * 16 + xi) * 3 + part) * 64 + (oc & 15) + 16 * (ic >> 3)) * 8 + (ic & 7)] = (uint16_t)(bits >> 16);
+                    }
+                }
             }
     }
     // bf16 configuration: round-to-nearest-even images for v_mfma_f32_16x16x32_bf16.
@@ -213,6 +231,8 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
                     const int kp = 32 * st + 8 * (lane >> 4) + j, win = kp >> 6, oc = kp & 63, n = 16 * t + (lane & 15);
                     fc1b[(((size_t)st * 8 + t) * 64 + lane) * 8 + j] = bf16(f1w[(size_t)n * 3136 + oc * 49 + win]);
                 }
+    SV_HIP(hipMalloc((void **)&ctx->w.conv2_wsplit, wsplit.size() * 2));
+    SV_HIP(hipMemcpy(ctx->w.conv2_wsplit, wsplit.data(), wsplit.size() * 2, hipMemcpyHostToDevice));
     SV_HIP(hipMalloc((void **)&ctx->w.conv2_bf16, w2b.size() * 2));
     SV_HIP(hipMemcpy(ctx->w.conv2_bf16, w2b.data(), w2b.size() * 2, hipMemcpyHostToDevice));
     SV_HIP(hipMalloc((void **)&ctx->w.fc1_bf16, fc1b.size() * 2));

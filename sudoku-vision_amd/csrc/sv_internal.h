@@ -19,6 +19,7 @@ struct sv_weights {
     float *conv2_b = nullptr;   // [64]
     float *fc1_wreg = nullptr;  // [196 chunk][8 t][64 lane][4 e] MFMA B-operand register image
     float *fc1_b = nullptr;     // [128]
+    unsigned short *conv2_wsplit = nullptr; // [4 nt][16 xi][3 parts][64 lane][8] U split into three bf16 parts (k_conv_features_wsplit)
     unsigned short *conv2_bf16 = nullptr; // [9 tap][4 t][64 lane][8] bf16 MFMA B image (bf16 configuration)
     unsigned short *fc1_bf16 = nullptr;   // [98 step][8 t][64 lane][8] bf16
     float *fc2_w = nullptr;     // [10][128]

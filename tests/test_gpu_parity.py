@@ -400,8 +400,9 @@ def test_bf16_configuration_digit_parity(golden_dir):
 
 
 def test_conv_algorithms_agree(golden_dir):
-    """Two independent conv2 implementations -- Winograd stream (default) and direct implicit GEMM (SV_CONV_ALGO=0) -- give
-    the same logits to ~1e-5 and the same digits; run in a subprocess because the choice is read once per process."""
+    """Three independent conv2 implementations -- Winograd stream on f32 MFMA (SV_CONV_ALGO=2), direct implicit GEMM (0) and the
+    Winograd stream on bf16 MFMA with three-way operand splitting (3) -- give the same logits to ~1e-5 and the same digits; run in
+    subprocesses because the choice is read once per process."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -414,14 +415,15 @@ def test_conv_algorithms_agree(golden_dir):
             "x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (500, 28, 28)).astype(np.uint8)).cuda()\n"
             "np.save(sys.argv[1], ctx.cnn_forward(x).cpu().numpy())\n")
     outs = []
-    for algo in ("2", "0"):
+    for algo in ("2", "0", "3"):
         path = f"/tmp/sv_conv_algo_{algo}.npy"
         env = dict(os.environ, SV_CONV_ALGO=algo)
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(path))
-    assert np.abs(outs[0] - outs[1]).max() <= 2e-5
-    assert (outs[0].argmax(1) == outs[1].argmax(1)).all()
+    for other in outs[1:]:
+        assert np.abs(outs[0] - other).max() <= 2e-5
+        assert (outs[0].argmax(1) == other.argmax(1)).all()
 
 
 def test_cnn_large_batch_frame_kernel(ctx, golden_dir):

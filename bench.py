@@ -141,8 +141,12 @@ def main():
     # second figure: the same pool with the host corner search in the loop (K1 -> D2H -> CPU contours -> K2 -> K3)
     e2e = None
     if args.e2e_passes > 0:
-        from sudoku_vision_amd.pipeline import FramePipeline
-        host_threads = max(1, min(16, (os.cpu_count() or 2) // max(world, 1)))   # the box's CPU share is 16 cores per GPU
+        from sudoku_vision_amd.pipeline import FramePipeline, host_cpu_budget
+        # the box's CPU share is 16 cores per GPU, enforced as a cgroup quota: stay two under it (this thread + the HIP runtime's)
+        budget = host_cpu_budget()
+        if budget > 16 * world:                      # no quota (or one far above the per-GPU share): split the host evenly over the ranks
+            budget //= world
+        host_threads = max(1, min(16, budget) - 2)
         pipe = FramePipeline(ctx, H, W, chunk=64 if n % 64 == 0 else 32, host_threads=host_threads)
         pipe.run(frames, out=out)                     # warm-up (page-locks, thread start)
         barrier()

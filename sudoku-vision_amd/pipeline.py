@@ -20,10 +20,27 @@ from . import host
 from .runtime import Context
 
 
+def host_cpu_budget():
+    """CPUs this process may actually use: the cgroup CPU quota when there is one (a box gives each GPU job 16 of the host's
+    256 logical CPUs through cpu.max; running more runnable threads than the quota gets the whole group throttled for the rest
+    of the period -- 30 ms stalls in the corner search), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(quota) // int(period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 class FramePipeline:
     def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1, glue=0, despeckle=True):
         self.ctx, self.H, self.W, self.chunk = ctx, H, W, chunk
-        self.host_threads = host_threads or max(1, (os.cpu_count() or 2) - 1)
+        self.host_threads = host_threads or max(1, host_cpu_budget() - 2)   # two CPUs left for this thread and the runtime's own
         self.min_area_ratio = min_area_ratio
         self.despeckle = despeckle
         self.glue = glue            # Context.GLUE_NORMALIZE, or GLUE_RUNPY for run.py's preprocess_cell (CLAHE + threshold)

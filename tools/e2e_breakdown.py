@@ -17,7 +17,8 @@ from sudoku_vision_amd.pipeline import FramePipeline  # noqa: E402
 from sudoku_vision_amd.synth import synth_frames  # noqa: E402
 import cnn_oracle  # noqa: E402
 
-threads = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+from sudoku_vision_amd.pipeline import host_cpu_budget  # noqa: E402
+threads = int(sys.argv[1]) if len(sys.argv) > 1 else max(1, host_cpu_budget() - 2)
 ctx = sva.default_context()
 ctx.load_state_dict(cnn_oracle.random_state_dict(1234))
 frames, corners, _ = synth_frames(256, 1080, 1920, seed=1234, device="cuda")

@@ -130,3 +130,13 @@ def test_run_pipeline_counterpart(ctx, golden_dir, tmp_path):
     Image.fromarray(np.full((480, 640, 3), 200, np.uint8)).save(blank, "JPEG", quality=90)
     nog = run_pipeline(blank, ctx=ctx)
     assert not nog.success and nog.error == "Grid detection failed: no quadrilateral found" and nog.original_image.shape == (480, 640, 3)
+
+
+def test_imdecode_noninterleaved_scans(ctx):
+    """A baseline file with one scan per component (re-encoded from a Pillow file in tests/test_jpeg.py) through both transports."""
+    from test_jpeg import _encode_noninterleaved
+    for h, w, sub in ((61, 83, 2), (50, 37, 1), (40, 40, 0)):
+        data = _encode_noninterleaved(encode(synth_image(h, w, 7 * h + w), quality=85, subsampling=sub))
+        want = pil_bgr(data)
+        for dense in (False, True):
+            assert (ctx.imdecode(data, dense=dense).cpu().numpy() == want).all(), (h, w, sub, dense)

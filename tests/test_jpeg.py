@@ -197,3 +197,140 @@ def test_host_jpeg_errors(host):
     Image.fromarray(synth_image(16, 16, 2)).convert("CMYK").save(cmyk, "JPEG")
     with pytest.raises(sva._native.NativeError, match="SV_ERR_UNSUPPORTED"):
         host.jpeg_parse(cmyk.getvalue())
+
+
+# ---- non-interleaved (one scan per component) baseline files ---------------------------------------------------------
+# Pillow only writes interleaved scans, so the test re-encodes a Pillow file: same tables and coefficients, three scans.
+def _parse_tables(data):
+    """(dqt segments raw, {(class, id): (counts[16], symbols)}, sof payload, component table selectors from the SOS)"""
+    pos, dqt, dht, sof, sel, app = 2, [], {}, None, None, []
+    while True:
+        assert data[pos] == 0xFF
+        m, L = data[pos + 1], int.from_bytes(data[pos + 2:pos + 4], "big")
+        seg = data[pos + 4:pos + 2 + L]
+        if m == 0xDB:
+            dqt.append(seg)
+        elif m == 0xC4:
+            s = seg
+            while s:
+                tc, th = s[0] >> 4, s[0] & 15
+                counts = list(s[1:17])
+                tot = sum(counts)
+                dht[(tc, th)] = (counts, list(s[17:17 + tot]))
+                s = s[17 + tot:]
+        elif m == 0xC0:
+            sof = seg
+        elif m in (0xE0, 0xE1):
+            app.append(data[pos:pos + 2 + L])
+        elif m == 0xDA:
+            ns = seg[0]
+            sel = {seg[1 + 2 * i]: (seg[2 + 2 * i] >> 4, seg[2 + 2 * i] & 15) for i in range(ns)}
+            return dqt, dht, sof, sel, app
+        pos += 2 + L
+
+
+def _huff_codes(counts, symbols):
+    codes, code, k = {}, 0, 0
+    for ln in range(1, 17):
+        for _ in range(counts[ln - 1]):
+            codes[symbols[k]] = (code, ln)
+            code += 1
+            k += 1
+        code <<= 1
+    return codes
+
+
+class _BitWriter:
+    def __init__(self):
+        self.out, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, value, length):
+        self.acc = (self.acc << length) | (value & ((1 << length) - 1))
+        self.n += length
+        while self.n >= 8:
+            b = (self.acc >> (self.n - 8)) & 0xFF
+            self.out.append(b)
+            if b == 0xFF:
+                self.out.append(0)
+            self.n -= 8
+
+    def flush(self):
+        if self.n:
+            self.put((1 << (8 - self.n)) - 1, 8 - self.n)
+        return bytes(self.out)
+
+
+def _encode_noninterleaved(data):
+    """Re-encodes a Pillow (interleaved, 3-component) baseline JPEG with one scan per component."""
+    info = o.jpeg_info(data)
+    coef, _ = o.jpeg_coefficients(data)
+    dqt, dht, sof, sel, app = _parse_tables(data)
+    H, W = info.height, info.width
+    hs = [info.h_samp, 1, 1]
+    vs = [info.v_samp, 1, 1]
+    mcux, mcuy = -(-W // (8 * info.h_samp)), -(-H // (8 * info.v_samp))
+    out = bytearray(b"\xff\xd8")
+    for a in app:
+        out += a
+    for q in dqt:
+        out += b"\xff\xdb" + (len(q) + 2).to_bytes(2, "big") + q
+    out += b"\xff\xc0" + (len(sof) + 2).to_bytes(2, "big") + sof
+    for (tc, th), (counts, symbols) in dht.items():
+        body = bytes([tc << 4 | th]) + bytes(counts) + bytes(symbols)
+        out += b"\xff\xc4" + (len(body) + 2).to_bytes(2, "big") + body
+    off = 0
+    zz = _ZZ
+    for c in range(3):
+        cid = sof[6 + 3 * c]
+        td, ta = sel[cid]
+        dc_codes, ac_codes = _huff_codes(*dht[(0, td)]), _huff_codes(*dht[(1, ta)])
+        bw, bh = mcux * hs[c], mcuy * vs[c]                                   # padded grid the coefficients are stored on
+        rw = -(-(-(-W * hs[c] // info.h_samp)) // 8)                          # real block grid of a non-interleaved scan
+        rh = -(-(-(-H * vs[c] // info.v_samp)) // 8)
+        out += b"\xff\xda" + (8).to_bytes(2, "big") + bytes([1, cid, td << 4 | ta, 0, 63, 0])
+        bwr, pred = _BitWriter(), 0
+        for by in range(rh):
+            for bx in range(rw):
+                blk = coef[off + (by * bw + bx) * 64: off + (by * bw + bx) * 64 + 64]
+                diff = int(blk[0]) - pred
+                pred = int(blk[0])
+                size = abs(diff).bit_length()
+                bwr.put(*dc_codes[size])
+                if size:
+                    bwr.put(diff if diff > 0 else diff + (1 << size) - 1, size)
+                run = 0
+                last = max([k for k in range(1, 64) if blk[zz[k]] != 0], default=0)
+                for k in range(1, last + 1):
+                    v = int(blk[zz[k]])
+                    if v == 0:
+                        run += 1
+                        continue
+                    while run > 15:
+                        bwr.put(*ac_codes[0xF0])
+                        run -= 16
+                    size = abs(v).bit_length()
+                    bwr.put(*ac_codes[run << 4 | size])
+                    bwr.put(v if v > 0 else v + (1 << size) - 1, size)
+                    run = 0
+                if last < 63:
+                    bwr.put(*ac_codes[0x00])
+        out += bwr.flush()
+        off += bw * bh * 64
+    return bytes(out + b"\xff\xd9")
+
+
+@pytest.mark.parametrize("h,w,sub", [(64, 80, 2), (61, 83, 2), (50, 37, 1), (40, 40, 0), (17, 9, 2)])
+def test_noninterleaved_scans(host, h, w, sub):
+    """One scan per component: MCU = one block of the component's own (unpadded) block grid.  The oracle, Pillow and the
+    product's host decoder agree on a file re-encoded that way, and it decodes to the same pixels as the interleaved original."""
+    original = encode(synth_image(h, w, 7 * h + w), quality=85, subsampling=sub)     # standard (complete) Huffman tables
+    data = _encode_noninterleaved(original)
+    assert data != original and data.count(b"\xff\xda") >= 3
+    want = pil_bgr(data)
+    assert (want == pil_bgr(original)).all()                                 # the re-encoding is lossless
+    assert (o.imdecode(data) == want).all()
+    info, coef, quant = host.jpeg_entropy_decode(data)
+    oc, oq = o.jpeg_coefficients(data)
+    assert (coef == oc).all() and (quant == oq).all()
+    info2, masks, offs, vals, _ = host.jpeg_entropy_decode_sparse(data)
+    assert (_densify(info2, masks, offs, vals) == oc).all()

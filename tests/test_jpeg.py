@@ -334,3 +334,15 @@ def test_noninterleaved_scans(host, h, w, sub):
     assert (coef == oc).all() and (quant == oq).all()
     info2, masks, offs, vals, _ = host.jpeg_entropy_decode_sparse(data)
     assert (_densify(info2, masks, offs, vals) == oc).all()
+
+
+def test_exif_orientation_big_endian(host):
+    """EXIF written Motorola-order ("MM"), as many cameras do: same orientation handling as the little-endian form Pillow writes."""
+    base = encode(synth_image(24, 40, 3), quality=90, subsampling=2)
+    for orient in (3, 6, 8):
+        tiff = b"MM\x00\x2a\x00\x00\x00\x08" + b"\x00\x01" + b"\x01\x12\x00\x03\x00\x00\x00\x01" + orient.to_bytes(2, "big") + b"\x00\x00" + b"\x00\x00\x00\x00"
+        seg = b"Exif\x00\x00" + tiff
+        data = base[:2] + b"\xff\xe1" + (len(seg) + 2).to_bytes(2, "big") + seg + base[2:]
+        assert Image.open(io.BytesIO(data)).getexif().get(0x0112) == orient     # Pillow reads the tag we wrote
+        assert o.jpeg_info(data).orientation == orient and host.jpeg_parse(data).orientation == orient
+        assert (o.imdecode(data) == pil_bgr(data)).all()

@@ -346,3 +346,26 @@ def test_exif_orientation_big_endian(host):
         assert Image.open(io.BytesIO(data)).getexif().get(0x0112) == orient     # Pillow reads the tag we wrote
         assert o.jpeg_info(data).orientation == orient and host.jpeg_parse(data).orientation == orient
         assert (o.imdecode(data) == pil_bgr(data)).all()
+
+
+def test_random_files_oracle_pillow_host(host):
+    """Seeded sweep over sizes, qualities, sub-samplings, restart intervals and table optimisation: the oracle equals Pillow
+    pixel for pixel, and the product's host decoder (dense and compact form) equals the oracle coefficient for coefficient."""
+    rs = np.random.RandomState(2024)
+    for it in range(40):
+        h, w = int(rs.randint(1, 120)), int(rs.randint(1, 160))
+        gray = it % 6 == 0
+        kw = dict(quality=int(rs.randint(1, 101)))
+        if not gray:
+            kw["subsampling"] = int(rs.randint(0, 3))
+        if it % 5 == 0:
+            kw["restart_marker_blocks"] = int(rs.randint(1, 7))
+        if it % 4 == 0:
+            kw["optimize"] = True
+        data = encode(synth_image(h, w, it, gray=gray), **kw)
+        assert (o.imdecode(data) == pil_bgr(data)).all(), (h, w, kw)
+        oc, oq = o.jpeg_coefficients(data)
+        info, coef, quant = host.jpeg_entropy_decode(data, threads=1 + it % 3)
+        assert (coef == oc).all() and (quant[:info.components] == oq).all(), (h, w, kw)
+        info2, masks, offs, vals, _ = host.jpeg_entropy_decode_sparse(data, threads=1 + it % 2)
+        assert (_densify(info2, masks, offs, vals) == oc).all(), (h, w, kw)

@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the frame -> digits hot path on MI355X (BASELINE.json metric: frames/s, 1080p -> 81 digits).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1 without a launcher: bench.py starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the hot path over one batch of synthetic 1080p frames already resident in HBM:
 K1 (frame -> binary image for the host corner search) + K2 (frame + homography -> 81 cells) +
-K3 (cells -> logits, digits).  Workload at every N: BASELINE.json configs[1] per GPU -- 256 synthetic
-1080p frames, fp32 CNN -- with the generator's ground-truth corners (device-only figure; the host
-corner search is reported separately once it is in the loop).  Frames shard by rank with no
-collective (weak scaling); the only torch.distributed use is the timing barrier and a MAX of elapsed.
+K3 (cells -> logits, digits).
 
-Prints ONE JSON line on rank 0.
+Workloads
+  configs1 (default)  BASELINE.json configs[1] per GPU: 256 synthetic 1080p frames per step, fp32 CNN, generator corners
+                      (device-only figure; the same line carries the end-to-end figure with the host corner search in the loop).
+                      Weak scaling: every rank owns its own 256-frame pool.
+  configs3            BASELINE.json configs[3]: 100,000 frames dealt round-robin (frame i -> rank i mod N, sharding.shard_indices),
+                      each rank cycling its 256-frame pool; a step = one pass over the 100,000 frames.  Strong scaling.
+  --precision bf16    BASELINE.json configs[4]: conv2 / fc1 on bf16 MFMA (digit-index parity only).
+
+Ranks never exchange data: the process group (gloo, host side -- no RCCL dependency) only lines the ranks
+up for timing and takes the MAX of their elapsed times.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -22,23 +28,31 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work per unit (restated in DESIGN.md)
+# algorithmic work per unit (restated in DESIGN.md section 4)
 BYTES_PER_FRAME = 9_916_344          # read 6,220,800 + <=1,555,200 ; write 2,073,600 + 63,504 + 3,240
 K1_BYTES_PER_FRAME = 6_220_800 + 2_073_600
 K2_BYTES_PER_FRAME = 1_555_200 + 63_504
-CONV_FLOP_PER_CELL = 451_584 + 7_225_344
-# what k_conv_features_wstream executes per cell: 1568 v_mfma_f32_16x16x4_f32 (Winograd F(2x2,3x3): 2.25x fewer multiplies than
-# the direct 3x3 convolution the algorithmic figure counts) + conv1 on the VALU + the two Winograd transforms' adds
-CONV_EXECUTED_FLOP_PER_CELL = 1568 * 2048 + 451_584 + 49 * 32 * 32 + 49 * 64 * 24
+CONV_FLOP_PER_CELL = 451_584 + 7_225_344          # direct 3x3 convolutions (conv1 + conv2), MAC = 2 FLOP
 FC_FLOP_PER_CELL = 802_816 + 2_560
 HBM_PEAK = 8.0e12                    # B/s, MI355X_MICROARCH.md
 FP32_MFMA_PEAK = 157.3e12            # FLOP/s, v_mfma_f32_* (= fp32 vector peak)
 BF16_MFMA_PEAK = 2.5e15              # FLOP/s dense, v_mfma_f32_*_bf16
 
 
+def conv_issued_flop_per_cell(info):
+    """FLOPs the default f32 conv kernel ISSUES per cell (what its roofline fraction is priced on): conv2 by Winograd
+    F(2x2,3x3) = `mfma_conv2` v_mfma_f32_16x16x4_f32 (2048 FLOP each; the direct convolution the algorithmic figure counts
+    would need 3600), conv1 either on the same MFMA (`mfma_conv1` instructions, zero-padded taps included) or on the VALU
+    (451,584 FLOP), plus the adds of the two Winograd transforms on the VALU."""
+    flop = (info["mfma_conv2"] + info["mfma_conv1"]) * 2048
+    if not info["mfma_conv1"]:
+        flop += 451_584
+    return flop + 49 * 32 * 32 + 49 * 64 * 24
+
+
 def cpu_baseline(frames_host, corners, sd, threads):
     """The oracle (CPU port of the reference arithmetic) on a bounded sample: K1+K2 in C, one frame per
-    thread; CNN with torch-CPU on all cells.  Baseline only."""
+    thread; CNN with torch-CPU on all cells.  Baseline only.  The one place in this file that touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from concurrent.futures import ThreadPoolExecutor
     import numpy as np
@@ -72,41 +86,52 @@ def cpu_baseline(frames_host, corners, sd, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--steps", type=int, default=None, help="default 10 (configs1) / 2 (configs3)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 2 (configs1) / 1 (configs3)")
+    ap.add_argument("--frames", type=int, default=256, help="frames in each GPU's resident pool (= frames per GPU per step in configs1)")
+    ap.add_argument("--workload", choices=["configs1", "configs3"], default="configs1")
+    ap.add_argument("--total-frames", type=int, default=100_000, help="configs3: frames dealt round-robin over the ranks per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE configs[1] (headline); bf16 = configs[4]: conv2/fc1 on bf16 MFMA, digit-index parity only")
     ap.add_argument("--e2e-passes", type=int, default=8, help="passes over the pool with the host corner search in the loop (0 = skip)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 10 if args.workload == "configs1" else 2
+    if args.warmup is None:
+        args.warmup = 2 if args.workload == "configs1" else 1
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                                       # no launcher: be the launcher (before anything touches the GPU)
+            from sudoku_vision_amd.sharding import launch_local_ranks
+            raise SystemExit(launch_local_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to benchmark a different GPU count than asked for")
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
     import sudoku_vision_amd as sva
     from sudoku_vision_amd import sharding
     rank, local_rank, world = sharding.env_rank_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # SV_BENCH_REHEARSE=1: rehearse the multi-rank code path on a one-GPU box (all ranks on cuda:0, gloo instead of RCCL)
+    # SV_BENCH_REHEARSE=1: rehearse the multi-rank code path on a one-GPU box (all ranks on cuda:0)
     rehearse = os.environ.get("SV_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible (SV_BENCH_REHEARSE=1 puts every rank on cuda:0)")
     torch.cuda.set_device(local_rank)
-    sharding.init("gloo" if rehearse else "nccl")          # RCCL; only for the timing barrier and the MAX of elapsed
-    dev = None if rehearse else torch.device("cuda", local_rank)
+    sharding.init()                                             # gloo; only for the timing barrier and the MAX of elapsed
 
-    from sudoku_vision_amd.synth import synth_frames
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import cnn_oracle
+    from sudoku_vision_amd.synth import random_state_dict, synth_frames
 
     ctx = sva.default_context()
     n = args.frames
     H, W = 1080, 1920
     frames, corners, _ = synth_frames(n, H, W, seed=1234 + rank, device="cuda")
-    sd = cnn_oracle.random_state_dict(1234)        # random-init weights of the DigitCNN architecture
+    sd = random_state_dict(1234)                                # random-init weights of the DigitCNN architecture
     ctx.load_state_dict(sd)
     ctx.reserve(n * 81)
     if args.precision == "bf16":
@@ -115,15 +140,32 @@ def main():
     out = {"logits": torch.empty((n, 81, 10), dtype=torch.float32, device="cuda"),
            "digits": torch.empty((n, 81), dtype=torch.uint8, device="cuda"),
            "conf": torch.empty((n, 81), dtype=torch.float32, device="cuda")}
+    binary = torch.empty((n, H, W), dtype=torch.uint8, device="cuda")
 
-    def step():
-        binary = ctx.preprocess(frames)              # K1: what the host corner search consumes
-        ctx.frames_to_digits(frames, minv, out=out)  # K2 -> K3
-        return binary
+    def batch(m):
+        """the hot path over the first m frames of the pool"""
+        ctx.preprocess(frames[:m], out=binary[:m])                                   # K1: what the host corner search consumes
+        ctx.frames_to_digits(frames[:m], minv[:m], out={k: v[:m] for k, v in out.items()})   # K2 -> K3
+
+    if args.workload == "configs1":
+        frames_per_step_rank, frames_per_step_job = n, n * world
+
+        def step():
+            batch(n)
+    else:
+        # frame i of the 100,000 goes to rank i mod world; the k-th frame a rank owns is its pool frame k mod n
+        mine = len(sharding.shard_indices(args.total_frames, rank, world))
+        frames_per_step_rank, frames_per_step_job = mine, args.total_frames
+
+        def step():
+            for _ in range(mine // n):
+                batch(n)
+            if mine % n:
+                batch(mine % n)
 
     def barrier():
         torch.cuda.synchronize()
-        sharding.barrier(dev)
+        sharding.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -136,11 +178,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     per_kernel = ctx.timing_end()
-    elapsed = sharding.max_over_ranks(elapsed, dev)
+    elapsed = sharding.max_over_ranks(elapsed)
 
     # second figure: the same pool with the host corner search in the loop (K1 -> D2H -> CPU contours -> K2 -> K3)
     e2e = None
-    if args.e2e_passes > 0:
+    if args.e2e_passes > 0 and args.workload == "configs1":
         from sudoku_vision_amd.pipeline import FramePipeline, host_cpu_budget
         # the box's CPU share is 16 cores per GPU, enforced as a cgroup quota: stay two under it (this thread + the HIP runtime's)
         budget = host_cpu_budget()
@@ -154,54 +196,75 @@ def main():
         res_e2e = pipe.run(frames, out=out, repeat=args.e2e_passes)     # the pool streamed e2e_passes times, pipeline kept full
         barrier()
         dt = time.perf_counter() - t1
-        dt = sharding.max_over_ranks(dt, dev)
+        dt = sharding.max_over_ranks(dt)
         err = np.abs(res_e2e["corners"].astype(np.float32)[:, :, None, :] - corners[:, None, :, :]).sum(-1).min(-1).max()
         e2e = {"value": n * args.e2e_passes * world / dt, "unit": "frames/s", "host_threads_per_gpu": host_threads,
                "grids_found": int(res_e2e["found"].sum()), "of": n, "max_corner_error_px": float(err),
-               "note": "K1 -> despeckle (exact speck filter) -> pinned D2H of the bit-packed binary (259 KB/frame over PCIe) -> C++ contour corner search on host threads -> K2 -> K3, 64-frame chunks triple-buffered"}
+               "note": pipe.describe()}
 
     if rank == 0:
-        total_frames = n * args.steps * world
+        total_frames = frames_per_step_job * args.steps
         fps = total_frames / elapsed
-        cells = n * 81
-        work = {"k_preprocess": ("hbm", K1_BYTES_PER_FRAME * n), "k_warp_cells": ("hbm", K2_BYTES_PER_FRAME * n),
-                "k_conv_features": ("mfma", CONV_FLOP_PER_CELL * cells), "k_fc_head": ("mfma", FC_FLOP_PER_CELL * cells)}
+        launched = frames_per_step_rank * args.steps               # frames rank 0 pushed through each kernel in the timed region
+        conv_info = ctx.conv_kernel_info()
+        per_frame = {"k_preprocess": ("hbm", K1_BYTES_PER_FRAME), "k_warp_cells": ("hbm", K2_BYTES_PER_FRAME),
+                     "k_conv_features": ("mfma", CONV_FLOP_PER_CELL * 81), "k_fc_head": ("mfma", FC_FLOP_PER_CELL * 81)}
         kernels = {}
         for name, (ms, cnt) in per_kernel.items():
             if not cnt:
                 continue
-            bound, units = work[name]
-            avg = ms / cnt * 1e-3
+            bound, units = per_frame[name]
+            avg = ms / cnt * 1e-3                                   # average launch duration (HIP events on the launch stream)
+            per_launch = units * launched / cnt                     # algorithmic bytes / FLOPs of an average launch
             peak = HBM_PEAK if bound == "hbm" else (BF16_MFMA_PEAK if args.precision == "bf16" else FP32_MFMA_PEAK)
-            ach = units / avg
-            kernels[name] = {"bound": bound, "avg_ms": ms / cnt, "launches": cnt,
-                             "achieved": ach / (1e9 if bound == "hbm" else 1e12), "peak": peak / (1e9 if bound == "hbm" else 1e12),
+            ach = per_launch / avg
+            scale = 1e9 if bound == "hbm" else 1e12
+            kernels[name] = {"bound": bound, "avg_ms": ms / cnt, "launches": cnt, "achieved": ach / scale, "peak": peak / scale,
                              "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": ach / peak}
+        if "k_conv_features" in kernels and args.precision == "f32":
+            # the f32 conv kernel does conv2 by Winograd: it issues fewer FLOPs than the direct convolution the algorithmic
+            # figure counts, so that figure can exceed the MFMA peak.  `frac` is priced on the FLOPs the kernel issues;
+            # the direct-convolution equivalent is kept beside it.
+            k = kernels["k_conv_features"]
+            k["algorithmic_equiv"], k["algorithmic_equiv_frac"] = k["achieved"], k["frac"]
+            issued = conv_issued_flop_per_cell(conv_info) * 81 * launched / k["launches"] / (k["avg_ms"] * 1e-3)
+            k["achieved"], k["frac"] = issued / 1e12, issued / FP32_MFMA_PEAK
+            k["mfma_busy_frac"] = (conv_info["mfma_conv2"] + conv_info["mfma_conv1"]) * 2048 * 81 * launched / k["launches"] / (k["avg_ms"] * 1e-3) / FP32_MFMA_PEAK
+            k["issued_flop_per_cell"] = conv_issued_flop_per_cell(conv_info)
+            k["algo"] = conv_info["name"]
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected
         # as MI355X_MICROARCH.md prescribes; collected on this same command at 256 frames, profiles/pmc_traffic.json)
         traffic, tf = None, os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf) and n == 256 and args.precision == "f32":
+        if os.path.exists(tf) and n == 256 and args.precision == "f32" and args.workload == "configs1":
             pmc = json.load(open(tf))
             traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
             for k in kernels:
                 kernels[k]["traffic"] = pmc.get(k, {}).get("hbm_bytes_per_launch")
         roofline = {"kernel": dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")}, "traffic": traffic}
-        if dom == "k_conv_features" and args.precision == "f32":
-            ex = CONV_EXECUTED_FLOP_PER_CELL * cells / (kernels[dom]["avg_ms"] * 1e-3)
-            roofline["executed"] = ex / 1e12
-            roofline["executed_frac"] = ex / FP32_MFMA_PEAK
-            roofline["note"] = ("achieved = algorithmic FLOPs of the direct convolution (SURVEY 8d) / kernel time; the kernel computes conv2 by Winograd "
-                                "F(2x2,3x3), 2.25x fewer multiplies, so the algorithmic rate can exceed the MFMA peak; executed = FLOPs actually issued "
-                                "(MFMA + conv1 + transform adds)")
+        if "algorithmic_equiv_frac" in kernels[dom]:
+            roofline.update({k: kernels[dom][k] for k in ("algorithmic_equiv", "algorithmic_equiv_frac", "mfma_busy_frac", "issued_flop_per_cell", "algo")})
+            roofline["note"] = ("achieved/frac = FLOPs the kernel issues (conv2 by Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 + conv1 + transform adds) / kernel time / "
+                                "157.3 TF; algorithmic_equiv = the direct 3x3 convolutions' 7,676,928 FLOP/cell (SURVEY 8d) / kernel time, which Winograd may push past the peak; "
+                                "mfma_busy_frac = MFMA instructions x 2048 FLOP only")
+        cfg_id = 3 if args.workload == "configs3" else (1 if args.precision == "f32" else 4)
+        if args.workload == "configs3":
+            wl = (f"configs[3]: {args.total_frames} synthetic 1080p frames per step dealt round-robin over {world} GPU(s) (frame i -> rank i mod N), "
+                  f"each rank cycling its resident {n}-frame pool in {n}-frame batches")
+        else:
+            wl = f"configs[{cfg_id}]: {n} synthetic 1080p frames per GPU per step"
+        wl += (f", HIP threshold + warp + 81-cell CNN {args.precision} forward, generator corners (device-only: the host corner search is not in "
+               "the timed region; see value_end_to_end)")
         res = {
-            "metric": "end-to-end frames/sec (1080p->81 digits)", "value": fps, "unit": "frames/s",
+            "metric": "frames/sec (1080p->81 digits)", "value": fps, "value_kind": "device_only",
+            "value_end_to_end": e2e["value"] if e2e else None, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"configs[{1 if args.precision == 'f32' else 4}]: {n} synthetic 1080p frames per GPU per step, HIP threshold + warp + 81-cell CNN {args.precision} forward, "
-                                   "generator corners (host corner search not in the timed region)",
-                       "frames_per_gpu": n, "height": H, "width": W, "weights": "random-init DigitCNN (seed 1234)",
-                       "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "higher_is_better": True, "scaling": "strong" if args.workload == "configs3" else "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": wl, "frames_per_gpu": n if args.workload == "configs1" else frames_per_step_rank,
+                       "frames_per_step": frames_per_step_job, "height": H, "width": W, "weights": "random-init DigitCNN (seed 1234)",
+                       "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, no data-path collective (gloo barrier for timing only)"},
+            "per_gpu_value": fps / world,
             "roofline": roofline,
             "kernels": kernels,
             "pipeline_hbm_frac": fps / world * BYTES_PER_FRAME / HBM_PEAK,
@@ -213,8 +276,7 @@ def main():
             m = min(n, 2 * threads)
             res["cpu_baseline"] = cpu_baseline(frames[:m].cpu().numpy(), corners[:m], sd, threads)
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    sharding.shutdown()
 
 
 if __name__ == "__main__":

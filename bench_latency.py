@@ -13,7 +13,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def main():
@@ -26,15 +25,14 @@ def main():
     import numpy as np
     import torch
     import sudoku_vision_amd as sva
-    from sudoku_vision_amd.synth import synth_frames
-    import cnn_oracle
+    from sudoku_vision_amd.synth import random_state_dict, synth_frames
 
     torch.cuda.set_device(0)
     ctx = sva.default_context()
     H, W = 1080, 1920
     pool, corners_gt, _ = synth_frames(32, H, W, seed=77, device="cuda")
     host_pool = [pool[i].cpu().pin_memory() for i in range(32)]
-    ctx.load_state_dict(cnn_oracle.random_state_dict(1234))
+    ctx.load_state_dict(random_state_dict(1234))
     ctx.reserve(81)
 
     frame_d = torch.empty((1, H, W, 3), dtype=torch.uint8, device="cuda")

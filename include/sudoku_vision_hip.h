@@ -76,6 +76,12 @@ int sv_ctx_reserve(sv_ctx *ctx, long max_cells);
 int sv_timing_begin(sv_ctx *ctx);
 int sv_timing_end(sv_ctx *ctx, double *ms_total /*host, 4*/, long *launches /*host, 4*/);
 
+/* Measurement aid: which f32 conv kernel sv_cnn_forward_* / sv_frames_to_digits launch in this process (SV_CONV_ALGO
+ * environment variable; the default is the Winograd stream kernel) and how many v_mfma_f32_16x16x4_f32 instructions
+ * (2048 FLOP each) it issues per 28x28 cell for conv2 and for conv1 (0 = conv1 runs on the VALU).  bench.py prices the
+ * kernel's roofline fraction on the work it issues, not on the direct convolution's FLOP count. */
+int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_conv2_per_cell, int *mfma_conv1_per_cell);
+
 /* Loads DigitCNN weights: `blob` [host] is the state_dict flattened in key order
  * conv1.weight[32,1,3,3] conv1.bias[32] conv2.weight[64,32,3,3] conv2.bias[64] fc1.weight[128,3136]
  * fc1.bias[128] fc2.weight[10,128] fc2.bias[10] = SV_CNN_PARAMS floats.
@@ -109,7 +115,11 @@ int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int 
  * sv_find_grid_corners_u8(despeckled) == sv_find_grid_corners_u8(binary).  out may equal binary.
  * packed (optional, needs W % 32 == 0): the result as 1 bit per pixel (LSB = leftmost, W/32 words per row) for a
  * cheap D2H copy -- when given, `out` is scratch (first pass only) and `packed` holds the result; feed it to
- * sv_find_grid_corners_bits_batch. */
+ * sv_find_grid_corners_bits_batch.
+ * PRECONDITION for the equality above: min_area_ratio * H * W > 61 * 61 (an erased component's bounding box is at most
+ * 62x62 px, so its contour area is at most 61*61; with a smaller area floor, e.g. frames under ~193x193 at the default
+ * ratio 0.1, the grid itself could be erased).  The library cannot check it (min_area_ratio belongs to the search);
+ * callers must (sudoku-vision_amd/pipeline.py does). */
 int sv_despeckle_u8(sv_ctx *ctx, const uint8_t *binary /*dev, n*H*W*/, int n, int H, int W,
                     uint8_t *out /*dev, n*H*W*/, uint32_t *packed /*dev, n*H*W/32, or NULL*/, void *stream);
 
@@ -160,6 +170,12 @@ int sv_solve_sudoku(const uint8_t *grid /*host, 81*/, uint8_t *solution /*host, 
  * minv: n*9 doubles (destination -> source). */
 int sv_corners_to_minv(const float *corners /*host*/, int n, int out_size, float inset_ratio,
                        double *minv /*host*/);
+
+/* The same for a batch in which single frames may be degenerate (order_points picks one point twice for a quad rotated
+ * near 45 degrees, cv/grid.py:79-91: the 8x8 system is then singular): ok[f] = 1 and minv[f] filled, or ok[f] = 0 and
+ * minv[f] = identity.  Never returns SV_ERR_DEGENERATE; the caller masks the frames with ok[f] = 0. */
+int sv_corners_to_minv_batch(const float *corners /*host*/, int n, int out_size, float inset_ratio,
+                             double *minv /*host*/, uint8_t *ok /*host, n*/);
 
 /* cv2.warpPerspective(image, M, (S,S)), cv/grid.py:131: bilinear, 1/32-px coordinates, 15-bit
  * weights, constant-0 border.  channels 1 or 3.  One image. */

@@ -193,7 +193,7 @@ int svo_jpeg_info_parse(const uint8_t *d, size_t len, svo_jpeg_info *o)
 }
 
 /* ---- entropy decoding, one bit at a time (T.81 F.2.2.3 DECODE / RECEIVE / EXTEND) ---- */
-typedef struct { const uint8_t *p, *end; int cur, n, hit_marker; } bitrd;
+typedef struct { const uint8_t *p, *end; int cur, n, hit_marker, starved; } bitrd;   /* starved: bits that are not in the file were consumed */
 
 static int getbit(bitrd *b)
 {
@@ -204,9 +204,9 @@ static int getbit(bitrd *b)
             if (c == 0xFF) {
                 int c2 = b->p < b->end ? *b->p : 0xD9;
                 if (c2 == 0) b->p++;
-                else { b->p--; b->hit_marker = 1; c = 0; }     /* a marker inside the scan: libjpeg feeds zero bits */
+                else { b->p--; b->hit_marker = 1; c = 0; b->starved = 1; }   /* a marker inside the scan: libjpeg feeds zero bits */
             }
-        }
+        } else b->starved = 1;                                 /* ... as it does past the end of the data (jdhuff.c: insufficient_data) */
         b->cur = c; b->n = 8;
     }
     b->n--;
@@ -276,7 +276,8 @@ static int decode_scans(const uint8_t *d, size_t len, const jpg *j0, size_t p, i
         }
         if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return -4;
         p += L;
-        bitrd b = {d + p, d + len, 0, 0, 0};
+        bitrd b = {d + p, d + len, 0, 0, 0, 0};
+        int dead = 0;                                           /* insufficient data: the rest of the restart interval stays zero */
         int pred[3] = {0, 0, 0};
         long nmcu;
         int mw, mh;
@@ -293,7 +294,7 @@ static int decode_scans(const uint8_t *d, size_t len, const jpg *j0, size_t p, i
                 const uint8_t *q = b.p;
                 while (q < b.end && *q != 0xFF) q++;            /* libjpeg also skips to the next marker */
                 while (q + 1 < b.end && q[1] == 0xFF) q++;
-                if (q + 1 < b.end && q[1] >= 0xD0 && q[1] <= 0xD7) { b.p = q + 2; b.hit_marker = 0; }
+                if (q + 1 < b.end && q[1] >= 0xD0 && q[1] <= 0xD7) { b.p = q + 2; b.hit_marker = 0; b.starved = 0; dead = 0; }
                 else return -1;
                 rst++;
                 pred[0] = pred[1] = pred[2] = 0;
@@ -306,6 +307,7 @@ static int decode_scans(const uint8_t *d, size_t len, const jpg *j0, size_t p, i
                     for (int h = 0; h < nh; h++) {
                         const int bx = mx * nh + h, by = my * nv + v;
                         int16_t *blk = coef + j->off[c] + ((long)by * j->bw[c] + bx) * 64;
+                        if (dead) continue;                     /* coef was cleared up front */
                         const int t = decode_sym(&b, &j->dc[td[i]]);
                         if (t > 15) return -1;
                         pred[i] += t ? receive_extend(&b, t) : 0;
@@ -318,6 +320,7 @@ static int decode_scans(const uint8_t *d, size_t len, const jpg *j0, size_t p, i
                             blk[ZZ[k]] = (int16_t)receive_extend(&b, sz);
                             k++;
                         }
+                        if (b.starved) { memset(blk, 0, 64 * sizeof(int16_t)); dead = 1; }   /* a block made of bits that are not there is dropped */
                     }
             }
         }

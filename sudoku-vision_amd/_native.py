@@ -22,6 +22,7 @@ SIGNATURES = {
     "sv_load_weights_f32": [_p, _p],
     "sv_timing_begin": [_p],
     "sv_timing_end": [_p, _p, _p],
+    "sv_conv_kernel_info": [_p, _p, _p, _p],
     "sv_gray_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
     "sv_blur_u8": [_p, _p, _i, _i, _i, _i, _p, _p],
     "sv_adaptive_threshold_u8": [_p, _p, _i, _i, _i, _i, _d, _i, _p, _p],
@@ -30,6 +31,7 @@ SIGNATURES = {
     "sv_despeckle_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
     "sv_find_grid_corners_bits_batch": [_p, _i, _i, _i, _d, _d, _p, _p, _i],
     "sv_corners_to_minv": [_p, _i, _i, _f, _p],
+    "sv_corners_to_minv_batch": [_p, _i, _i, _f, _p, _p],
     "sv_find_grid_corners_u8": [_p, _i, _i, _pd, _d, _d, _p],
     "sv_find_grid_corners_batch_u8": [_p, _i, _i, _i, _pd, _pd, _d, _d, _p, _p, _i],
     "sv_find_contours_u8": [_p, _i, _i, _pd, _p, _l, _p, _i, _p, _p],

@@ -38,13 +38,13 @@ struct HuffTable {
         int code = 0, k = 0;
         for (int len = 1; len <= 16; len++) {
             delta[len] = k - code;
+            if (code + counts[len - 1] > (1 << len)) return false;  // over-subscribed table: reject before look[] is indexed with its codes
             for (int i = 0; i < counts[len - 1]; i++, k++, code++) {
                 if (len <= kLook) {
                     const int first = code << (kLook - len), span = 1 << (kLook - len);
                     for (int j = 0; j < span; j++) look[first + j] = (uint16_t)((len << 8) | vals[k]);
                 }
             }
-            if (code > (1 << len)) return false;                   // over-subscribed table
             maxcode[len] = code << (16 - len);
             code <<= 1;
         }
@@ -240,6 +240,7 @@ struct BitStream {
     const uint8_t *p, *end;
     uint64_t acc = 0;                   // bits left-aligned
     int have = 0;
+    long fake = 0;                      // zero bits appended after the interval's last byte (they sit at the tail of the buffer)
 
     BitStream(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
 
@@ -261,10 +262,13 @@ struct BitStream {
                 c = *p++;
                 if (c == 0xFF && p < end && *p == 0x00) p++;        // byte stuffing; the interval ends before any real marker
             }
+            else fake += 8;
             acc |= (uint64_t)c << (56 - have);
             have += 8;
         }
     }
+    // true once decoding has consumed bits that are not in the file (a truncated or corrupt interval)
+    inline bool starved() const { return (long)have < fake; }
     inline unsigned peek16() const { return (unsigned)(acc >> 48); }
     inline void drop(int n) { acc <<= n; have -= n; }
     inline int take_signed(int s)       // RECEIVE + EXTEND (T.81 F.2.2.1)
@@ -300,13 +304,17 @@ struct Scan {
 struct DenseOut { int16_t *coef; };
 struct SparseOut { uint64_t *masks; uint32_t *offs; int16_t *vals; };
 
-// Decodes MCUs [m0, m1) of a scan from one restart interval's bytes.  Sparse: values are appended from index `vpos` on;
-// returns the index after the last value written (dense: 0).
+// Decodes MCUs [m0, m1) of a scan from one restart interval's bytes.  Sparse: values are appended from index `vpos` on, never
+// at or beyond `vlimit`; returns the index after the last value written (dense: 0).
+// Insufficient data, as libjpeg handles it (jdhuff.c: insufficient_data, reset at every restart): once decoding needs bits the
+// interval does not hold, the block being decoded and every later block of the interval stay zero (they reconstruct as mid-grey),
+// which is what cv2.imread / Pillow(LOAD_TRUNCATED_IMAGES) show for the tail of a cut file.
 template <bool SPARSE, class Out>
-long decode_interval(const Header &h, const Scan &scan, const uint8_t *b, const uint8_t *e, long m0, long m1, const Out &out, long vpos)
+long decode_interval(const Header &h, const Scan &scan, const uint8_t *b, const uint8_t *e, long m0, long m1, const Out &out, long vpos, long vlimit)
 {
     BitStream bs(b, e);
     int pred[3] = {0, 0, 0};
+    bool dead = false;
     for (long mi = m0; mi < m1; mi++) {
         const int mx = (int)(mi % scan.mcu_cols), my = (int)(mi / scan.mcu_cols);
         for (int i = 0; i < scan.ns; i++) {
@@ -323,12 +331,20 @@ long decode_interval(const Header &h, const Scan &scan, const uint8_t *b, const 
                         blk = out.coef + bi * 64;
                         memset(blk, 0, 64 * sizeof(int16_t));       // cleared while the lines are about to be written anyway
                     }
+                    if (dead) {
+                        if constexpr (SPARSE) { out.masks[bi] = 0; out.offs[bi] = (uint32_t)vstart; }
+                        continue;
+                    }
+                    bool full = false;                              // sparse: the interval's stretch of the value stream is used up
                     bs.refill();
                     const int t = bs.symbol(dct) & 15;
                     if (t) pred[i] += bs.take_signed(t);
-                    if constexpr (SPARSE) { if ((int16_t)pred[i]) { mask = 1; out.vals[vpos++] = (int16_t)pred[i]; } }
-                    else blk[0] = (int16_t)pred[i];
-                    for (int k = 1; k < 64;) {
+                    if constexpr (SPARSE) {
+                        if ((int16_t)pred[i]) {
+                            if (vpos < vlimit) { mask = 1; out.vals[vpos++] = (int16_t)pred[i]; } else full = true;
+                        }
+                    } else blk[0] = (int16_t)pred[i];
+                    for (int k = 1; k < 64 && !full;) {
                         bs.refill();
                         const int32_t f = act.fast_ac[bs.peek16() >> (16 - kLook)];
                         int val;
@@ -348,9 +364,18 @@ long decode_interval(const Header &h, const Scan &scan, const uint8_t *b, const 
                             if (k > 63) break;
                             val = bs.take_signed(size);
                         }
-                        if constexpr (SPARSE) { if ((int16_t)val) { mask |= 1ull << k; out.vals[vpos++] = (int16_t)val; } }
-                        else blk[kNatural[k]] = (int16_t)val;
+                        if constexpr (SPARSE) {
+                            if ((int16_t)val) {
+                                if (vpos < vlimit) { mask |= 1ull << k; out.vals[vpos++] = (int16_t)val; } else full = true;
+                            }
+                        } else blk[kNatural[k]] = (int16_t)val;
                         k++;
+                    }
+                    if (bs.starved() || full) {                     // this block was (partly) made of bits that are not there: drop it and the rest
+                        dead = true;
+                        mask = 0;
+                        vpos = vstart;
+                        if constexpr (!SPARSE) memset(blk, 0, 64 * sizeof(int16_t));
                     }
                     if constexpr (SPARSE) { out.masks[bi] = mask; out.offs[bi] = (uint32_t)vstart; }
                 }
@@ -382,11 +407,12 @@ size_t split_intervals(const uint8_t *d, size_t size, size_t pos, std::vector<st
 template <bool SPARSE, class Out>
 int entropy_decode(const uint8_t *d, size_t size, Header &h, const Out &out, int threads, long vals_cap, long *vals_used)
 {
-    bool cleared = false;                                          // interleaved scans reach (and clear) every block
+    bool first = true;
     size_t pos = h.first_scan;
-    int covered = 0;
+    unsigned covered = 0;                                          // bit c: component c has been decoded
+    const unsigned all = (1u << h.ncomp) - 1;
     long vbase = 0;                                                // sparse: where the next scan's value regions start
-    while (covered < h.ncomp) {
+    while (covered != all) {
         const uint8_t *s;
         int n;
         const int m = next_segment(d, size, pos, s, n);
@@ -402,16 +428,20 @@ int entropy_decode(const uint8_t *d, size_t size, Header &h, const Out &out, int
             while (c < h.ncomp && h.comp[c].id != s[1 + 2 * i]) c++;
             const int td = s[2 + 2 * i] >> 4, ta = s[2 + 2 * i] & 15;
             if (c == h.ncomp || td > 3 || ta > 3 || !h.dc[td].defined || !h.ac[ta].defined) return sv_fail(SV_ERR_BAD_ARG, "jpeg: scan refers to an undefined component or table");
+            if (covered >> c & 1) return sv_fail(SV_ERR_BAD_ARG, "jpeg: component %d appears in more than one scan (or twice in one)", c);
+            covered |= 1u << c;
             scan.sc[i] = {c, td, ta, scan.ns == 1 ? 1 : h.comp[c].h, scan.ns == 1 ? 1 : h.comp[c].v};
         }
         const uint8_t *tail = s + 1 + 2 * scan.ns;
         if (tail[0] != 0 || tail[1] != 63 || tail[2] != 0) return sv_fail(SV_ERR_UNSUPPORTED, "jpeg: spectral selection / successive approximation in a sequential file");
+        if (first && scan.ns < h.ncomp) {                          // only a full interleave reaches (and clears) every block: a
+            if constexpr (SPARSE) {                                // component's own block grid leaves the MCU padding blocks out
+                memset(out.masks, 0, (size_t)(h.coef_count / 64) * sizeof(uint64_t));
+                memset(out.offs, 0, (size_t)(h.coef_count / 64) * sizeof(uint32_t));
+            } else memset(out.coef, 0, (size_t)h.coef_count * sizeof(int16_t));
+        }
+        first = false;
         if (scan.ns == 1) {                                        // non-interleaved: the component's own block grid
-            if (h.ncomp > 1 && !cleared) {                         // ... which does not reach the MCU padding blocks
-                if constexpr (SPARSE) memset(out.masks, 0, (size_t)(h.coef_count / 64) * sizeof(uint64_t));
-                else memset(out.coef, 0, (size_t)h.coef_count * sizeof(int16_t));
-                cleared = true;
-            }
             const Component &c = h.comp[scan.sc[0].comp];
             scan.mcu_cols = ((h.width * c.h + h.hmax - 1) / h.hmax + 7) / 8;
             scan.mcu_rows = ((h.height * c.v + h.vmax - 1) / h.vmax + 7) / 8;
@@ -436,13 +466,12 @@ int entropy_decode(const uint8_t *d, size_t size, Header &h, const Out &out, int
         const Header &hc = h;
         WorkerPool::instance().parallel_for((int)need, threads, [&](int k) {
             const long m0 = (long)k * per, m1 = std::min(nmcu, m0 + per);
-            vend[k] = decode_interval<SPARSE>(hc, scan, d + iv[k].first, d + iv[k].second, m0, m1, out, vstart[k]);
+            vend[k] = decode_interval<SPARSE>(hc, scan, d + iv[k].first, d + iv[k].second, m0, m1, out, vstart[k], SPARSE ? vstart[k + 1] : 0);
         });
         if constexpr (SPARSE) {
             vbase = vstart[need];
             if (vals_used) *vals_used = vend[need - 1];            // everything the kernels can reference lies below this index
         }
-        covered += scan.ns;
     }
     return SV_OK;
 }

@@ -1008,6 +1008,26 @@ int svk_softmax_topk(const float *logits, long B, int k, u8 *index, float *prob,
     return SV_OK;
 }
 
+// cross-check aid: 0 = direct implicit GEMM (k_conv_features_pc), 2 = Winograd stream on f32 MFMA (default), 3 = Winograd stream on
+// bf16 MFMA with three-way operand splitting (k_conv_features_wsplit)
+static int conv_algo_env()
+{
+    static const int algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 2;
+    return algo;
+}
+
+extern "C" int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_conv2_per_cell, int *mfma_conv1_per_cell)
+{
+    if (!ctx || !algo || !mfma_conv2_per_cell || !mfma_conv1_per_cell) return sv_fail(SV_ERR_BAD_ARG, "sv_conv_kernel_info: NULL argument");
+    const int a = conv_algo_env();
+    *algo = (a == 2 || a == 3) ? a : 0;
+    // Winograd: 49 tiles x 16 xi x 8 k-steps x 4 N tiles / 16 tiles per M tile; direct: 196 positions / 16 x 72 k-steps x 4 N tiles
+    // (the bf16-split kernel's MFMAs are bf16 ones: reported as 0 f32 MFMAs)
+    *mfma_conv2_per_cell = a == 2 ? 1568 : (a == 3 ? 0 : 3600);
+    *mfma_conv1_per_cell = 0;
+    return SV_OK;
+}
+
 int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
 {
     const sv_weights &w = ctx->w;
@@ -1017,9 +1037,7 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
         if (rc) return rc;
         x = ctx->cells2;
     }
-    // cross-check aid: 0 = direct implicit GEMM (k_conv_features_pc), 2 = Winograd stream on f32 MFMA (default), 3 = Winograd stream on
-    // bf16 MFMA with three-way operand splitting (k_conv_features_wsplit)
-    static const int conv_algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 2;
+    const int conv_algo = conv_algo_env();
     if (conv_algo == 3 && ((uintptr_t)x & 3) == 0) {
         long cpw = (B + ctx->num_cus - 1) / ctx->num_cus;
         if (cpw < 1) cpw = 1;

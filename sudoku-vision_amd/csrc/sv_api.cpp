@@ -349,26 +349,41 @@ bool invert3(const double *S, double *D)
 
 }  // namespace
 
+static bool corners_to_minv_one(const float *corners, int out_size, float inset_ratio, double *minv)
+{
+    float o[8], in[8];
+    order_points(corners, o);
+    // float32 numpy arithmetic of cv/grid.py:113-121
+    const float cx = (((o[0] + o[2]) + o[4]) + o[6]) / 4.f, cy = (((o[1] + o[3]) + o[5]) + o[7]) / 4.f;
+    for (int i = 0; i < 4; i++) {
+        const float dx = cx - o[2 * i], dy = cy - o[2 * i + 1];
+        const float dist = std::sqrt(dx * dx + dy * dy);
+        const float amt = dist * inset_ratio;
+        in[2 * i] = o[2 * i] + (dx / dist) * amt;
+        in[2 * i + 1] = o[2 * i + 1] + (dy / dist) * amt;
+    }
+    const float S = (float)(out_size - 1);
+    const float dst[8] = {0, 0, S, 0, S, S, 0, S};
+    double M[9];
+    return perspective_transform(in, dst, M) && invert3(M, minv);
+}
+
 extern "C" int sv_corners_to_minv(const float *corners, int n, int out_size, float inset_ratio, double *minv)
 {
     if (!corners || !minv || n <= 0 || out_size < 2) return sv_fail(SV_ERR_BAD_ARG, "sv_corners_to_minv: bad argument");
-    for (int f = 0; f < n; f++) {
-        float o[8], in[8];
-        order_points(corners + 8 * f, o);
-        // float32 numpy arithmetic of cv/grid.py:113-121
-        const float cx = (((o[0] + o[2]) + o[4]) + o[6]) / 4.f, cy = (((o[1] + o[3]) + o[5]) + o[7]) / 4.f;
-        for (int i = 0; i < 4; i++) {
-            const float dx = cx - o[2 * i], dy = cy - o[2 * i + 1];
-            const float dist = std::sqrt(dx * dx + dy * dy);
-            const float amt = dist * inset_ratio;
-            in[2 * i] = o[2 * i] + (dx / dist) * amt;
-            in[2 * i + 1] = o[2 * i + 1] + (dy / dist) * amt;
-        }
-        const float S = (float)(out_size - 1);
-        const float dst[8] = {0, 0, S, 0, S, S, 0, S};
-        double M[9];
-        if (!perspective_transform(in, dst, M) || !invert3(M, minv + 9 * f))
+    for (int f = 0; f < n; f++)
+        if (!corners_to_minv_one(corners + 8 * f, out_size, inset_ratio, minv + 9 * f))
             return sv_fail(SV_ERR_DEGENERATE, "sv_corners_to_minv: frame %d: corners do not define a homography", f);
+    return SV_OK;
+}
+
+extern "C" int sv_corners_to_minv_batch(const float *corners, int n, int out_size, float inset_ratio, double *minv, uint8_t *ok)
+{
+    if (!corners || !minv || !ok || n <= 0 || out_size < 2) return sv_fail(SV_ERR_BAD_ARG, "sv_corners_to_minv_batch: bad argument");
+    static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int f = 0; f < n; f++) {
+        ok[f] = corners_to_minv_one(corners + 8 * f, out_size, inset_ratio, minv + 9 * f) ? 1 : 0;
+        if (!ok[f]) memcpy(minv + 9 * f, ident, sizeof ident);
     }
     return SV_OK;
 }

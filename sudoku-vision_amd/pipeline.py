@@ -7,7 +7,9 @@ software-pipelined for a resident pool of frames:
 Chunks of frames are double-buffered: while the host searches chunk i, the GPU thresholds chunk i+1 and
 classifies chunk i-1.  `glue` selects what sits between extract_cells and the model (see include/sudoku_vision_hip.h sv_glue).
 A frame whose grid is not found gets found=False and digits 0 (the reference
-returns "Grid detection failed" for it, pipeline/run.py:268-272)."""
+returns "Grid detection failed" for it, pipeline/run.py:268-272); so does a frame whose four corners do not define a
+homography (order_points, cv/grid.py:79-91, returns one point twice for a quad rotated near 45 degrees; the reference
+warps garbage for that image) -- one such frame never affects the others of its batch."""
 import os
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -42,13 +44,15 @@ class FramePipeline:
         self.ctx, self.H, self.W, self.chunk = ctx, H, W, chunk
         self.host_threads = host_threads or max(1, host_cpu_budget() - 2)   # two CPUs left for this thread and the runtime's own
         self.min_area_ratio = min_area_ratio
-        self.despeckle = despeckle
+        # the speck filter is exact only while nothing it can erase (bounding box <= 62x62 px, area <= 61*61) reaches the
+        # search's area floor (include/sudoku_vision_hip.h, sv_despeckle_u8): small frames go through unfiltered
+        self.despeckle = bool(despeckle) and min_area_ratio * H * W > 61 * 61
         self.glue = glue            # Context.GLUE_NORMALIZE, or GLUE_RUNPY for run.py's preprocess_cell (CLAHE + threshold)
         dev = ctx.device
         self.s_pre = torch.cuda.Stream(dev)       # K1 + D2H
         self.s_cls = torch.cuda.Stream(dev)       # H2D + K2 + K3
         # D2H payload: with despeckle on and W % 32 == 0 the binary crosses PCIe as 1 bit per pixel (W/32 words per row)
-        self.packed = despeckle and W % 32 == 0
+        self.packed = self.despeckle and W % 32 == 0
         if self.packed:
             self.pinned = [torch.empty((chunk, H, W // 32), dtype=torch.int32).pin_memory() for _ in range(3)]
             self.dev_bits = [torch.empty((chunk, H, W // 32), dtype=torch.int32, device=dev) for _ in range(3)]
@@ -66,10 +70,15 @@ class FramePipeline:
             corners, found = host.find_grid_corners_bits_batch(self.pinned[slot][:m].numpy(), self.H, self.W, self.min_area_ratio, 0.02, self.host_threads)
         else:
             corners, found = host.find_grid_corners_batch(self.pinned[slot][:m].numpy(), self.min_area_ratio, 0.02, self.host_threads)
-        safe = corners.astype(np.float32)
-        safe[~found] = np.array([[0, 0], [449, 0], [449, 449], [0, 449]], np.float32)      # any valid quad; result is masked
-        self.minv_pin[slot][:m] = torch.from_numpy(Context.corners_to_minv(safe).reshape(m, 9))
-        return corners, found
+        minv, ok = Context.corners_to_minv_batch(corners.astype(np.float32))    # not-found frames hold zeros: degenerate, identity, masked
+        self.minv_pin[slot][:m] = torch.from_numpy(minv.reshape(m, 9))
+        return corners, found & ok
+
+    def describe(self):
+        d2h = (f"pinned D2H of the bit-packed binary ({self.H * self.W // 8 // 1000} KB/frame over PCIe)" if self.packed
+               else f"pinned D2H of the binary ({self.H * self.W // 1000} KB/frame over PCIe)")
+        return (f"K1 -> {'despeckle (exact speck filter) -> ' if self.despeckle else ''}{d2h} -> C++ contour corner search on "
+                f"{self.host_threads} host threads -> K2 -> K3, {self.chunk}-frame chunks triple-buffered")
 
     def run(self, frames, out=None, repeat=1):
         """frames u8 [n,H,W,3] on the context's device -> dict(digits u8[n,81], logits f32[n,81,10], conf f32[n,81],

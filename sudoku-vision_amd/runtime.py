@@ -98,6 +98,15 @@ class Context:
         _native.check(_native.lib().sv_timing_end(self._h, ms, cnt), "sv_timing_end")
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNELS)}
 
+    CONV_ALGO_NAMES = {0: "k_conv_features_pc (direct implicit GEMM, f32 MFMA)", 2: "k_conv_features_wstream (Winograd F(2x2,3x3), f32 MFMA)",
+                       3: "k_conv_features_wsplit (Winograd, bf16 MFMA with 3-way operand split)"}
+
+    def conv_kernel_info(self):
+        """Which f32 conv kernel this process launches and the f32 MFMA instructions it issues per cell (sv_conv_kernel_info)."""
+        a, m2, m1 = C.c_int(), C.c_int(), C.c_int()
+        _native.check(_native.lib().sv_conv_kernel_info(self._h, C.byref(a), C.byref(m2), C.byref(m1)), "sv_conv_kernel_info")
+        return {"algo": a.value, "name": self.CONV_ALGO_NAMES.get(a.value, str(a.value)), "mfma_conv2": m2.value, "mfma_conv1": m1.value}
+
     # ---- K1 -----------------------------------------------------------------------------------
     def gray(self, bgr):
         bgr, pitch, fstride = _frame_layout(bgr)
@@ -119,12 +128,15 @@ class Context:
                                                              _ptr(out), _stream_ptr()), "sv_adaptive_threshold_u8")
         return out
 
-    def preprocess(self, frames):
+    def preprocess(self, frames, out=None):
         """frames u8 [n,H,W,3] on device (rows may be padded, frames may have gaps) -> binary u8 [n,H,W]
-        (preprocess_for_grid_detection)."""
+        (preprocess_for_grid_detection).  out: optional contiguous u8 [n,H,W] tensor to write into."""
         frames, pitch, fstride = _frame_layout(frames)
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
-        out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        elif out.shape != (n, H, W) or out.dtype != torch.uint8 or not out.is_contiguous():
+            raise TypeError("out must be a contiguous uint8 tensor of shape [n,H,W]")
         _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
         return out
 
@@ -147,6 +159,17 @@ class Context:
         _native.check(_native.lib().sv_corners_to_minv(c.ctypes.data_as(C.c_void_p), c.shape[0], int(output_size), float(inset_ratio),
                                                        out.ctypes.data_as(C.c_void_p)), "sv_corners_to_minv")
         return out
+
+    @staticmethod
+    def corners_to_minv_batch(corners, output_size=450, inset_ratio=0.0):
+        """As corners_to_minv, but a degenerate quad does not raise: -> (minv float64 [n,3,3], ok bool [n]); minv[f] is the
+        identity where ok[f] is False."""
+        c = np.ascontiguousarray(np.asarray(corners, dtype=np.float32).reshape(-1, 8))
+        out = np.empty((c.shape[0], 3, 3), np.float64)
+        ok = np.empty(c.shape[0], np.uint8)
+        _native.check(_native.lib().sv_corners_to_minv_batch(c.ctypes.data_as(C.c_void_p), c.shape[0], int(output_size), float(inset_ratio),
+                                                             out.ctypes.data_as(C.c_void_p), ok.ctypes.data_as(C.c_void_p)), "sv_corners_to_minv_batch")
+        return out, ok.astype(bool)
 
     def minv_to_device(self, minv):
         return torch.from_numpy(np.ascontiguousarray(minv, np.float64)).to(self.device)

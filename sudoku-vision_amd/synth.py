@@ -48,8 +48,14 @@ def _homography(src, dst):
     return np.concatenate([h, np.ones((n, 1))], 1).reshape(n, 3, 3)
 
 
-def synth_frames(n, H=1080, W=1920, seed=1234, device="cpu", chunk=8):
-    """-> frames u8 [n,H,W,3] (BGR, on `device`), corners f32 [n,4,2] (numpy), puzzle u8 [n,9,9] (numpy)."""
+def synth_frames(n, H=1080, W=1920, seed=1234, device="cpu", chunk=8, noise="torch"):
+    """-> frames u8 [n,H,W,3] (BGR, on `device`), corners f32 [n,4,2] (numpy), puzzle u8 [n,9,9] (numpy).
+    noise="torch": N(0,4) / N(0,3) from the device's generator (fast; the values depend on the device and the torch build).
+    noise="int": integer noise (sums of three uniform integers, same spread) from numpy's RandomState -- every operation that
+    follows is a single correctly-rounded IEEE operation, so with device="cpu" the frames are bit-identical on every machine;
+    this is what the committed golden checksums (tests/golden/make_cv_goldens.py) are made from."""
+    if noise not in ("torch", "int"):
+        raise ValueError("noise must be 'torch' or 'int'")
     rs = np.random.RandomState(seed)
     side = 0.76 * min(H, W)
     cx, cy = W / 2 + rs.uniform(-0.03, 0.03, n) * W, H / 2 + rs.uniform(-0.02, 0.02, n) * H
@@ -94,8 +100,31 @@ def synth_frames(n, H=1080, W=1920, seed=1234, device="cpu", chunk=8):
         lv = torch.from_numpy(level[s:e]).to(dev, torch.float32).reshape(m, 1, 1)
         g = torch.from_numpy(grad[s:e]).to(dev, torch.float32)
         paper = lv + g[:, 0].reshape(m, 1, 1) * (xs / W - 0.5) + g[:, 1].reshape(m, 1, 1) * (ys / H - 0.5)
-        paper = paper + 4.0 * torch.randn((m, H, W), generator=gen, device=dev)
-        val = torch.where(ink, paper * 0.0 + 45.0 + 3.0 * torch.randn((m, H, W), generator=gen, device=dev), paper)
+        if noise == "int":
+            n1 = torch.from_numpy(rs.randint(-4, 5, (3, m, H, W)).sum(0).astype(np.float32)).to(dev)      # sd 4.5
+            n2 = torch.from_numpy(rs.randint(-3, 4, (3, m, H, W)).sum(0).astype(np.float32)).to(dev)      # sd 3.5
+        else:
+            n1 = 4.0 * torch.randn((m, H, W), generator=gen, device=dev)
+            n2 = 3.0 * torch.randn((m, H, W), generator=gen, device=dev)
+        paper = paper + n1
+        val = torch.where(ink, paper * 0.0 + 45.0 + n2, paper)
         t = torch.from_numpy(tint[s:e]).to(dev, torch.float32).reshape(m, 1, 1, 3)
         frames[s:e] = (val[..., None] + t).round().clamp(0, 255).to(torch.uint8)
     return frames, corners.astype(np.float32), puzzle
+
+
+_CNN_KEYS = ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
+_CNN_SHAPES = ((32, 1, 3, 3), (32,), (64, 32, 3, 3), (64,), (128, 3136), (128,), (10, 128), (10,))
+
+
+def random_state_dict(seed: int):
+    """Random-init weights of the DigitCNN architecture (ml/model.py:22-32) for benchmarks: nn.Conv2d / nn.Linear default
+    ranges, U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases, drawn from numpy's RandomState so the values do not
+    depend on the torch version.  state_dict keys and shapes as the reference's."""
+    rs = np.random.RandomState(seed)
+    sd, bound = {}, 1.0
+    for key, shape in zip(_CNN_KEYS, _CNN_SHAPES):
+        if key.endswith("weight"):
+            bound = 1.0 / np.sqrt(float(np.prod(shape[1:])))
+        sd[key] = torch.from_numpy(rs.uniform(-bound, bound, size=shape).astype(np.float32))
+    return sd

@@ -1,0 +1,250 @@
+"""GPU (-m gpu): the HIP path against COMMITTED golden values (tests/golden/cv_goldens.json, photo_goldens.npz) -- not only
+against the live oracle --, all five data/test_images photos end to end, BASELINE configs[2] (hipGraph capture / replay) and the
+multi-rank bench entry rehearsed on one GPU.  Same parity caveat as tests/test_cv_goldens.py: the CV goldens come from a
+restatement of OpenCV (cv2 is not in the image)."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import cnn_oracle
+import sv_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+G = json.load(open(os.path.join(GOLDEN, "cv_goldens.json")))
+LOGIT_TOL = 1e-4
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _trained(golden_dir):
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    return {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+
+
+@pytest.mark.parametrize("rec", G["synthetic"], ids=lambda r: f"{r['H']}x{r['W']}-s{r['seed']}-{r['index']}")
+def test_synthetic_goldens(ctx, rec):
+    """K1 binary, homography bytes and K2 cells of seeded frames: SHA-256 equal to the committed values."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.synth import synth_frames
+    frames, corners, _ = synth_frames(rec["n"], rec["H"], rec["W"], seed=rec["seed"], noise="int")      # on the CPU: bit-stable
+    i = rec["index"]
+    assert sha(frames[i].numpy()) == rec["frame_sha256"]
+    d = frames[i:i + 1].cuda()
+    binary = ctx.preprocess(d)[0].cpu().numpy()
+    assert sha(binary) == rec["binary_sha256"]
+    minv = sva.Context.corners_to_minv(corners[i:i + 1])
+    assert sha(minv[0]) == rec["minv_sha256"]
+    cells = ctx.warp_cells(d, ctx.minv_to_device(minv))[0].cpu().numpy()
+    assert sha(cells) == rec["cells_sha256"]
+    got = sva.host.find_grid_corners(binary)
+    assert (None if got is None else got.tolist()) == rec["found_corners"]
+
+
+@pytest.mark.parametrize("rec", G["photos"], ids=lambda r: r["file"])
+def test_all_reference_photos_end_to_end(ctx, golden_dir, rec):
+    """data/test_images/sample_{1..5}.jpg (north_star: "bit-exact digit-index parity on data/test_images"; the reference's note
+    "CV success rate on test images: 4/5", tests/test_integration.py:261).  Per photo, everything on the product path:
+    GPU JPEG decode (= the PIL-decoded frame the goldens were made from), K1 binary SHA-256, host corner search, K2 cells,
+    run.py glue + DigitCNN with the trained weights: digits equal, logits <= 1e-4.  The photo without a grid goes through the
+    `None` path: find_grid_contour -> None, run_pipeline -> "Grid detection failed: no quadrilateral found" (cv/grid.py:51-52,71;
+    pipeline/run.py:268-272)."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd import imgcodecs
+    from sudoku_vision_amd.pipeline import recognize_image, run_pipeline
+    path = os.path.join(golden_dir, rec["file"])
+    sd = _trained(golden_dir)
+    ctx.load_state_dict(sd)
+    frame = imgcodecs.imread(path, device=True, ctx=ctx)
+    assert list(frame.shape) == rec["shape"] and sha(frame.cpu().numpy()) == rec["frame_sha256"]
+    binary = ctx.preprocess(frame[None])[0].cpu().numpy()
+    assert sha(binary) == rec["binary_sha256"]
+    corners = sva.host.find_grid_corners(binary)
+    assert (None if corners is None else corners.tolist()) == rec["corners"]
+    res = run_pipeline(path, ctx=ctx)
+    if rec["corners"] is None:
+        assert recognize_image(frame, ctx=ctx) is None
+        assert not res.success and res.error == "Grid detection failed: no quadrilateral found"
+        assert res.warped_grid is None and res.cells == [] and res.predictions == []
+        return
+    P = np.load(os.path.join(golden_dir, "photo_goldens.npz"))
+    key = rec["file"].split(".")[0]
+    minv = sva.Context.corners_to_minv(corners[None].astype(np.float32))
+    assert sha(minv[0]) == rec["minv_sha256"]
+    cells = ctx.warp_cells(frame[None], ctx.minv_to_device(minv))[0].cpu().numpy()
+    assert sha(cells) == rec["cells_sha256"] and (cells == P[key + "_cells"]).all()
+    out = recognize_image(frame, ctx=ctx)                                  # run.py order incl. preprocess_cell
+    assert (out["digits"] == P[key + "_digits"]).all()
+    assert np.abs(out["logits"] - P[key + "_logits"]).max() <= LOGIT_TOL
+    assert (np.stack(res.cells) == P[key + "_cells"]).all()                # run_pipeline: warp 450x450 then extract_cells = the fused K2
+    assert [p.digit if p.is_original else 0 for p in res.predictions] == P[key + "_digits"].tolist()
+    assert res.recognized_grid == [[int(P[key + "_digits"][r * 9 + c]) for c in range(9)] for r in range(9)]
+
+
+def test_hipgraph_capture_replay_configs2(ctx, golden_dir):
+    """BASELINE configs[2]: the per-frame path with its two device segments captured in hipGraphs exactly as bench_latency.py
+    does (segment 1: K1 -> despeckle -> bit-packed binary; segment 2: K2 -> K3), call order of pipeline/run.py:261-302.
+    Replayed on four different frames: K1 binary and cells bit-exact, logits <= 1e-4, digits equal to the oracle's; the host search
+    on the despeckled bits finds what the oracle's search finds on the raw binary.  Capture itself proves the library makes no
+    hipMalloc / synchronising call once sv_ctx_reserve has sized the scratch (either would abort the capture); device memory in
+    use does not change across replays."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.synth import synth_frames
+    H, W = 1080, 1920
+    pool, _, _ = synth_frames(4, H, W, seed=77, device="cuda")
+    pool[3] = 200                                                          # a frame without a grid
+    host_pool = [pool[i].cpu().pin_memory() for i in range(4)]
+    sd = _trained(golden_dir)
+    ctx.load_state_dict(sd)
+    ctx.reserve(81)
+    frame_d = torch.empty((1, H, W, 3), dtype=torch.uint8, device="cuda")
+    k1_d = torch.empty((1, H, W), dtype=torch.uint8, device="cuda")
+    scratch_d = torch.empty((1, H, W), dtype=torch.uint8, device="cuda")
+    bits_d = torch.empty((1, H, W // 32), dtype=torch.int32, device="cuda")
+    bits_h = torch.empty((1, H, W // 32), dtype=torch.int32).pin_memory()
+    minv_h = torch.empty((1, 9), dtype=torch.float64).pin_memory()
+    minv_d = torch.zeros((1, 9), dtype=torch.float64, device="cuda")
+    minv_d[0, 0] = minv_d[0, 4] = minv_d[0, 8] = 1
+    out = {"logits": torch.empty((1, 81, 10), device="cuda"), "digits": torch.empty((1, 81), dtype=torch.uint8, device="cuda"),
+           "conf": torch.empty((1, 81), device="cuda"), "cells": torch.empty((1, 81, 28, 28), dtype=torch.uint8, device="cuda")}
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        frame_d[0].copy_(host_pool[0], non_blocking=True)
+        ctx.despeckle(ctx.preprocess(frame_d, out=k1_d), out=scratch_d, packed=bits_d)       # warm-up outside capture
+        ctx.frames_to_digits(frame_d, minv_d, out=out, glue=ctx.GLUE_RUNPY)
+        stream.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=stream):
+            ctx.despeckle(ctx.preprocess(frame_d, out=k1_d), out=scratch_d, packed=bits_d)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=stream):
+            ctx.frames_to_digits(frame_d, minv_d, out=out, glue=ctx.GLUE_RUNPY)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    found = 0
+    for i in (0, 1, 2, 3, 1):
+        with torch.cuda.stream(stream):
+            frame_d[0].copy_(host_pool[i], non_blocking=True)
+            g1.replay()
+            bits_h.copy_(bits_d, non_blocking=True)
+            stream.synchronize()
+            cc, ff = sva.host.find_grid_corners_bits_batch(bits_h.numpy(), H, W, threads=1)
+            img = host_pool[i].numpy()
+            binary = o.preprocess_for_grid_detection(img)
+            assert (k1_d[0].cpu().numpy() == binary).all()
+            want = o.find_grid_contour(binary)
+            assert bool(ff[0]) == (want is not None)
+            if want is None:
+                continue
+            assert (cc[0] == np.asarray(want).reshape(4, 2)).all()
+            found += 1
+            minv_h.copy_(torch.from_numpy(sva.Context.corners_to_minv(cc[:1].astype(np.float32)).reshape(1, 9)))
+            minv_d.copy_(minv_h, non_blocking=True)
+            g2.replay()
+            stream.synchronize()
+        cells = o.warp_cells(img, cc[0].astype(np.float32))
+        assert (out["cells"][0].cpu().numpy() == cells).all()
+        el, ed, _ = cnn_oracle.predict(sd, o.cells_to_input(o.preprocess_cells(cells))[:, None])
+        assert np.abs(out["logits"][0].cpu().numpy() - el.numpy()).max() <= LOGIT_TOL
+        assert (out["digits"][0].cpu().numpy() == ed.numpy()).all()
+    assert found == 4
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0                           # replays allocate nothing (library scratch included)
+
+
+def _bench(args, env=None, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=dict(os.environ, **(env or {})),
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_starts_its_own_ranks(ctx):
+    """`python bench.py --gpus 2` with no outer launcher: two ranks (both on cuda:0 under SV_BENCH_REHEARSE=1), n_gpus = 2 in
+    the line, weak scaling counts both ranks' frames; configs[3]'s round-robin workload at a small total."""
+    res = _bench(["--gpus", "2", "--frames", "32", "--steps", "3", "--warmup", "1", "--e2e-passes", "0", "--no-cpu-baseline"],
+                 env={"SV_BENCH_REHEARSE": "1"})
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak" and res["value_kind"] == "device_only"
+    assert res["config"]["frames_per_step"] == 64
+    assert abs(res["value"] - 64 * 3 / (res["ms_per_step"] * 3e-3)) <= 1e-6 * res["value"]
+    assert 0 < res["roofline"]["frac"] <= 1.0
+    res3 = _bench(["--gpus", "2", "--workload", "configs3", "--total-frames", "301", "--frames", "32", "--steps", "2", "--warmup", "1"],
+                  env={"SV_BENCH_REHEARSE": "1"})
+    assert res3["n_gpus"] == 2 and res3["scaling"] == "strong" and res3["config"]["frames_per_step"] == 301
+    assert res3["config"]["frames_per_gpu"] == 151                        # rank 0 owns frames 0, 2, ..., 300
+    assert res3["kernels"]["k_preprocess"]["launches"] == 2 * 5           # 151 = 4 x 32 + 23: five launches per step
+
+
+def test_bench_single_gpu_line_is_honest(ctx):
+    """--gpus 1 line: roofline.frac <= 1 and reproducible from its own fields, device-only and end-to-end values labelled."""
+    res = _bench(["--frames", "64", "--steps", "3", "--warmup", "1", "--e2e-passes", "2", "--no-cpu-baseline"])
+    rf = res["roofline"]
+    assert res["n_gpus"] == 1 and res["value_kind"] == "device_only"
+    assert res["value_end_to_end"] == res["end_to_end_with_host_corner_search"]["value"] < res["value"]
+    assert 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    if rf["kernel"] == "k_conv_features":
+        k = res["kernels"]["k_conv_features"]
+        assert abs(rf["achieved"] * 1e12 - rf["issued_flop_per_cell"] * 81 * 64 / (k["avg_ms"] * 1e-3)) <= 1e-6 * rf["achieved"] * 1e12
+
+
+def test_degenerate_quad_does_not_abort_the_batch(ctx, golden_dir):
+    """A quad for which order_points (cv/grid.py:79-91) returns a point twice -- here a diamond, TR == BR -- makes the 8x8
+    system singular.  In a batch that frame alone is reported not found (digits 0); the others are unaffected."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.pipeline import FramePipeline
+    bad = np.array([[100, 0], [210, 100], [100, 200], [0, 95]], np.float32)
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_DEGENERATE"):
+        sva.Context.corners_to_minv(bad[None])
+    minv, ok = sva.Context.corners_to_minv_batch(np.stack([bad, bad + 7, np.array([[10, 10], [300, 12], [305, 290], [8, 300]], np.float32)]))
+    assert ok.tolist() == [False, False, True] and (minv[0] == np.eye(3)).all()
+    # in the pipeline: a frame that shows a filled diamond (the search finds it; its four corners are the degenerate case)
+    ctx.load_state_dict(_trained(golden_dir))
+    frames, corners, _ = _frames_cuda(4, 540, 960, 8)
+    yy, xx = torch.meshgrid(torch.arange(540, device="cuda"), torch.arange(960, device="cuda"), indexing="ij")
+    frames[2] = 220
+    frames[2][((xx - 480).abs() + (yy - 270).abs()) < 200] = 30
+    pipe = FramePipeline(ctx, 540, 960, chunk=4, host_threads=2)
+    res = pipe.run(frames)
+    assert res["found"].tolist() == [True, True, False, True]
+    assert (res["digits"][2] == 0).all()
+    good = [0, 1, 3]
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(res["corners"][good].astype(np.float32)))
+    assert torch.equal(res["digits"][good], ctx.frames_to_digits(frames[good].contiguous(), minv)["digits"])
+
+
+def _frames_cuda(n, H, W, seed):
+    from sudoku_vision_amd.synth import synth_frames
+    return synth_frames(n, H, W, seed=seed, device="cuda")
+
+
+def test_small_frames_skip_the_speck_filter(ctx, golden_dir):
+    """sv_despeckle_u8 is exact only while min_area_ratio*H*W > 61*61: on a 150x150 frame (floor 2250 px) a grid that fits
+    a 64x64 tile would be erased.  FramePipeline sends such frames through unfiltered and finds what the plain search finds."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.pipeline import FramePipeline
+    ctx.load_state_dict(_trained(golden_dir))
+    H = W = 150
+    frames = torch.full((2, H, W, 3), 215, dtype=torch.uint8, device="cuda")
+    frames[0, 50:110, 48:108] = 25                                         # a 60x60 dark square: area 3481 > 0.1*150*150
+    pipe = FramePipeline(ctx, H, W, chunk=2, host_threads=1)
+    assert not pipe.despeckle and not pipe.packed
+    res = pipe.run(frames)
+    b = ctx.preprocess(frames).cpu().numpy()
+    want = [sva.host.find_grid_corners(b[i]) for i in range(2)]
+    assert want[0] is not None and want[1] is None
+    assert res["found"].tolist() == [True, False] and (res["corners"][0] == want[0]).all()
+    # the filter itself, applied regardless, would have lost it: the guard is what keeps the pipeline equal to the reference
+    f = ctx.despeckle(ctx.preprocess(frames)).cpu().numpy()
+    assert sva.host.find_grid_corners(f[0]) is None or (sva.host.find_grid_corners(f[0]) == want[0]).all()
+    big = FramePipeline(ctx, 1080, 1920, chunk=2, host_threads=1)
+    assert big.despeckle and big.packed

@@ -502,7 +502,7 @@ def test_full_size_batch_properties(ctx, golden_dir):
       * K1 output is binary and identical whether a frame is processed alone, in a ragged sub-batch or in the full batch;
       * K2 cells likewise (bit-exact); digits equal, logits within 1e-5 across batch shapes (the fc kernel's summation order
         depends on the batch size, the conv kernel's does not);
-      * round-robin shards (N = 2, 3) recombine to the unsharded result -- the multi-GPU partitioning loses nothing;
+      * round-robin shards (N = 2, 3, 8) recombine to the unsharded result -- the multi-GPU partitioning loses nothing;
       * frames 0, 101 and 255 against the oracle: binary and cells bit-exact, logits <= 1e-4, digits equal."""
     import sudoku_vision_amd as sva
     from sudoku_vision_amd import sharding
@@ -525,7 +525,7 @@ def test_full_size_batch_properties(ctx, golden_dir):
         assert torch.equal(part["digits"], full["digits"][lo:hi])
         assert (part["logits"] - full["logits"][lo:hi]).abs().max().item() <= 1e-5
     # round-robin shards recombine
-    for world in (2, 3):
+    for world in (2, 3, 8):
         digits = torch.empty_like(full["digits"])
         for rank in range(world):
             idx = torch.tensor(sharding.shard_indices(n, rank, world), device="cuda")

@@ -369,3 +369,90 @@ def test_random_files_oracle_pillow_host(host):
         assert (coef == oc).all() and (quant[:info.components] == oq).all(), (h, w, kw)
         info2, masks, offs, vals, _ = host.jpeg_entropy_decode_sparse(data, threads=1 + it % 2)
         assert (_densify(info2, masks, offs, vals) == oc).all(), (h, w, kw)
+
+
+# ---- damaged files: no write past a buffer, libjpeg's insufficient-data behaviour ----------------------------
+def _pil_truncated(data):
+    """Pillow's decode of a cut file (LOAD_TRUNCATED_IMAGES): the rows libjpeg-turbo completed, then mid-grey."""
+    from PIL import ImageFile
+    ImageFile.LOAD_TRUNCATED_IMAGES = True
+    try:
+        return pil_bgr(data)
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = False
+
+
+@pytest.mark.parametrize("kw", [dict(quality=90, subsampling=2), dict(quality=85, subsampling=0),
+                                dict(quality=85, subsampling=2, restart_marker_rows=1), dict(quality=85, subsampling=1, restart_marker_blocks=5)])
+def test_truncated_files_stay_inside_their_buffers(host, kw):
+    """A file cut anywhere after its first scan header decodes without error into: every block the remaining bits hold, then zero
+    blocks (libjpeg: insufficient_data).  The sparse form never uses more values than the capacity sv_jpeg_parse promised (the
+    round-1 build wrote 7.0 M values into a 2.4 M buffer here).  Product == oracle; rows above the cut == Pillow; the tail is grey."""
+    h, w = 240, 320
+    data = encode(synth_image(h, w, 77), **kw)
+    full = pil_bgr(data)
+    sos = data.index(b"\xff\xda")
+    body = len(data) - sos
+    for frac in (0.15, 0.4, 0.5, 0.77, 0.98):
+        cut = data[:sos + 14 + int(frac * (body - 14))]
+        if kw.get("restart_marker_rows") or kw.get("restart_marker_blocks"):
+            # with restart markers a cut file has too few intervals: rejected cleanly (a decoder may also resynchronise; cv2 shows grey)
+            import sudoku_vision_amd as sva
+            try:
+                info, masks, offs, vals, quant = host.jpeg_entropy_decode_sparse(cut, threads=2)
+            except sva._native.NativeError as e:
+                assert "SV_ERR_BAD_ARG" in str(e)
+                continue
+        else:
+            info, masks, offs, vals, quant = host.jpeg_entropy_decode_sparse(cut, threads=2)
+        assert len(vals) <= info.sparse_capacity
+        _, coef, _ = host.jpeg_entropy_decode(cut)
+        oc, oq = o.jpeg_coefficients(cut)
+        assert (coef == oc).all() and (_densify(info, masks, offs, vals) == oc).all()
+        img = o.imdecode(cut)
+        pil = _pil_truncated(cut)
+        good = int(np.argmin((pil == full).all(axis=(1, 2))))          # first row Pillow could not complete
+        assert good > 0 and (img[:max(good - 16, 0)] == full[:max(good - 16, 0)]).all()
+        if frac < 0.9:                                                   # (at 0.98 the cut is inside the last MCU row)
+            assert (img[-8:] == 128).all() and (pil[-8:] == 128).all()
+
+
+def test_truncated_photo_capacity(host):
+    """The advisor's reproduction: the fixture photo cut to 605,593 and 205,593 bytes."""
+    data = open(os.path.join(GOLDEN, "sample_4.jpg"), "rb").read()
+    for keep in (605593, 205593):
+        info, masks, offs, vals, quant = host.jpeg_entropy_decode_sparse(data[:keep], threads=1)
+        assert len(vals) <= info.sparse_capacity
+        assert (_densify(info, masks, offs, vals) == o.jpeg_coefficients(data[:keep])[0]).all()
+
+
+def test_oversubscribed_dht_is_rejected(host):
+    """SOI + a DHT whose 255 one-bit codes pass the total <= 256 check: rejected before the look-up table is indexed with them
+    (the round-1 build wrote ~130 k entries into a 1024-entry table)."""
+    import sudoku_vision_amd as sva
+    counts = bytes([255] + [0] * 15)
+    seg = bytes([0x00]) + counts + bytes(range(255))
+    evil = b"\xff\xd8" + b"\xff\xc4" + (len(seg) + 2).to_bytes(2, "big") + seg + b"\xff\xd9"
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_BAD_ARG"):
+        host.jpeg_parse(evil)
+    for c in ([0, 5] + [0] * 14, [3] + [0] * 15, [1, 1, 1, 1, 1, 1, 1, 1, 1, 4] + [0] * 6):      # 5 two-bit codes, 3 one-bit codes, 4 after a full prefix chain
+        tot = sum(c)
+        seg = bytes([0x10]) + bytes(c) + bytes(range(tot))
+        evil = b"\xff\xd8" + b"\xff\xc4" + (len(seg) + 2).to_bytes(2, "big") + seg + b"\xff\xd9"
+        with pytest.raises(sva._native.NativeError, match="SV_ERR_BAD_ARG"):
+            host.jpeg_parse(evil)
+
+
+def test_repeated_scan_component_is_rejected(host):
+    """A non-interleaved file whose second scan repeats the first component never finishes `covered` by counting: rejected."""
+    import sudoku_vision_amd as sva
+    data = _encode_noninterleaved(encode(synth_image(40, 40, 3), quality=85, subsampling=0))
+    host.jpeg_entropy_decode(data)                                       # the well-formed file decodes
+    first = data.index(b"\xff\xda")
+    second = data.index(b"\xff\xda", first + 2)
+    ln = int.from_bytes(data[second + 2:second + 4], "big")
+    seg = bytearray(data[second:second + 2 + ln])
+    seg[5] = data[first + 5]                                             # component selector of scan 2 := that of scan 1
+    bad = data[:second] + bytes(seg) + data[second + 2 + ln:]
+    with pytest.raises(sva._native.NativeError, match="SV_ERR_BAD_ARG"):
+        host.jpeg_entropy_decode(bad)

@@ -37,17 +37,23 @@ FC_FLOP_PER_CELL = 802_816 + 2_560
 HBM_PEAK = 8.0e12                    # B/s, MI355X_MICROARCH.md
 FP32_MFMA_PEAK = 157.3e12            # FLOP/s, v_mfma_f32_* (= fp32 vector peak)
 BF16_MFMA_PEAK = 2.5e15              # FLOP/s dense, v_mfma_f32_*_bf16
+F16_MFMA_PEAK = 2.5e15               # FLOP/s dense, v_mfma_f32_*_f16 (same rate as bf16)
 
 
-def conv_issued_flop_per_cell(info):
-    """FLOPs the default f32 conv kernel ISSUES per cell (what its roofline fraction is priced on): conv2 by Winograd
-    F(2x2,3x3) = `mfma_conv2` v_mfma_f32_16x16x4_f32 (2048 FLOP each; the direct convolution the algorithmic figure counts
-    would need 3600), conv1 either on the same MFMA (`mfma_conv1` instructions, zero-padded taps included) or on the VALU
-    (451,584 FLOP), plus the adds of the two Winograd transforms on the VALU."""
-    flop = (info["mfma_conv2"] + info["mfma_conv1"]) * 2048
+def issued_flop_per_cell(info):
+    """FLOPs the CNN kernels ISSUE per cell (what their roofline fractions are priced on) -> (conv, fc, peak FLOP/s of the pipe).
+    Default pair (algo 4): v_mfma_f32_16x16x32_f16 instructions (16384 FLOP each; three partial products per f32-grade product,
+    conv1's K padded 16 -> 32) against the dense f16 MFMA peak.  f32-MFMA kernels: conv2 by Winograd F(2x2,3x3) (1568
+    v_mfma_f32_16x16x4_f32 of 2048 FLOP, where the direct convolution needs 3600) or direct, conv1 and the Winograd transforms' adds on
+    the VALU, fc1 as 802,816 FLOP padded 81 -> 96 rows, against the f32 MFMA peak."""
+    if info["mfma_f16_conv"]:
+        return info["mfma_f16_conv"] * 16384, info["mfma_f16_fc"] * 16384, F16_MFMA_PEAK
+    conv = (info["mfma_conv2"] + info["mfma_conv1"]) * 2048
     if not info["mfma_conv1"]:
-        flop += 451_584
-    return flop + 49 * 32 * 32 + 49 * 64 * 24
+        conv += 451_584
+    if info["algo"] == 2:
+        conv += 49 * 32 * 32 + 49 * 64 * 24
+    return conv, FC_FLOP_PER_CELL * 96 // 81, FP32_MFMA_PEAK
 
 
 def cpu_baseline(frames_host, corners, sd, threads):
@@ -221,17 +227,19 @@ def main():
             scale = 1e9 if bound == "hbm" else 1e12
             kernels[name] = {"bound": bound, "avg_ms": ms / cnt, "launches": cnt, "achieved": ach / scale, "peak": peak / scale,
                              "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": ach / peak}
-        if "k_conv_features" in kernels and args.precision == "f32":
-            # the f32 conv kernel does conv2 by Winograd: it issues fewer FLOPs than the direct convolution the algorithmic
-            # figure counts, so that figure can exceed the MFMA peak.  `frac` is priced on the FLOPs the kernel issues;
-            # the direct-convolution equivalent is kept beside it.
-            k = kernels["k_conv_features"]
-            k["algorithmic_equiv"], k["algorithmic_equiv_frac"] = k["achieved"], k["frac"]
-            issued = conv_issued_flop_per_cell(conv_info) * 81 * launched / k["launches"] / (k["avg_ms"] * 1e-3)
-            k["achieved"], k["frac"] = issued / 1e12, issued / FP32_MFMA_PEAK
-            k["mfma_busy_frac"] = (conv_info["mfma_conv2"] + conv_info["mfma_conv1"]) * 2048 * 81 * launched / k["launches"] / (k["avg_ms"] * 1e-3) / FP32_MFMA_PEAK
-            k["issued_flop_per_cell"] = conv_issued_flop_per_cell(conv_info)
-            k["algo"] = conv_info["name"]
+        if args.precision == "f32":
+            # `frac` of the CNN kernels is priced on the FLOPs they ISSUE on the pipe they issue them on; the direct f32 convolution /
+            # matrix product the algorithmic figure counts is kept beside it as the f32-equivalent rate
+            conv_f, fc_f, pipe_peak = issued_flop_per_cell(conv_info)
+            for name, per_cell in (("k_conv_features", conv_f), ("k_fc_head", fc_f)):
+                if name not in kernels:
+                    continue
+                k = kernels[name]
+                k["algorithmic_equiv"], k["algorithmic_equiv_frac_of_f32_peak"] = k["achieved"], k["frac"]
+                issued = per_cell * 81 * launched / k["launches"] / (k["avg_ms"] * 1e-3)
+                k["achieved"], k["peak"], k["frac"] = issued / 1e12, pipe_peak / 1e12, issued / pipe_peak
+                k["issued_flop_per_cell"], k["algo"] = per_cell, conv_info["name"]
+                k["pipe"] = "v_mfma_f32_16x16x32_f16" if conv_info["mfma_f16_conv"] else "v_mfma_f32_16x16x4_f32"
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected
         # as MI355X_MICROARCH.md prescribes; collected on this same command at 256 frames, profiles/pmc_traffic.json)
@@ -242,11 +250,10 @@ def main():
             for k in kernels:
                 kernels[k]["traffic"] = pmc.get(k, {}).get("hbm_bytes_per_launch")
         roofline = {"kernel": dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")}, "traffic": traffic}
-        if "algorithmic_equiv_frac" in kernels[dom]:
-            roofline.update({k: kernels[dom][k] for k in ("algorithmic_equiv", "algorithmic_equiv_frac", "mfma_busy_frac", "issued_flop_per_cell", "algo")})
-            roofline["note"] = ("achieved/frac = FLOPs the kernel issues (conv2 by Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32 + conv1 + transform adds) / kernel time / "
-                                "157.3 TF; algorithmic_equiv = the direct 3x3 convolutions' 7,676,928 FLOP/cell (SURVEY 8d) / kernel time, which Winograd may push past the peak; "
-                                "mfma_busy_frac = MFMA instructions x 2048 FLOP only")
+        if "algorithmic_equiv" in kernels[dom]:
+            roofline.update({k: kernels[dom][k] for k in ("algorithmic_equiv", "algorithmic_equiv_frac_of_f32_peak", "issued_flop_per_cell", "algo", "pipe")})
+            roofline["note"] = ("achieved/frac = FLOPs the kernel issues on its matrix pipe / kernel time / that pipe's dense peak; algorithmic_equiv = the direct "
+                                "f32 convolution / matrix product's FLOPs (SURVEY 8d) / kernel time")
         cfg_id = 3 if args.workload == "configs3" else (1 if args.precision == "f32" else 4)
         if args.workload == "configs3":
             wl = (f"configs[3]: {args.total_frames} synthetic 1080p frames per step dealt round-robin over {world} GPU(s) (frame i -> rank i mod N), "
@@ -261,6 +268,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.workload == "configs3" else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
+            "arithmetic": (conv_info["name"] + "; logits within 1e-4 of the PyTorch-CPU f32 model (measured ~1e-6), digits equal"
+                           if args.precision == "f32" else "bf16 operands, f32 accumulation; digit-index parity only"),
             "config": {"workload": wl, "frames_per_gpu": n if args.workload == "configs1" else frames_per_step_rank,
                        "frames_per_step": frames_per_step_job, "height": H, "width": W, "weights": "random-init DigitCNN (seed 1234)",
                        "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, no data-path collective (gloo barrier for timing only)"},

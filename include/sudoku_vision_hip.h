@@ -76,11 +76,13 @@ int sv_ctx_reserve(sv_ctx *ctx, long max_cells);
 int sv_timing_begin(sv_ctx *ctx);
 int sv_timing_end(sv_ctx *ctx, double *ms_total /*host, 4*/, long *launches /*host, 4*/);
 
-/* Measurement aid: which f32 conv kernel sv_cnn_forward_* / sv_frames_to_digits launch in this process (SV_CONV_ALGO
- * environment variable; the default is the Winograd stream kernel) and how many v_mfma_f32_16x16x4_f32 instructions
- * (2048 FLOP each) it issues per 28x28 cell for conv2 and for conv1 (0 = conv1 runs on the VALU).  bench.py prices the
- * kernel's roofline fraction on the work it issues, not on the direct convolution's FLOP count. */
-int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_conv2_per_cell, int *mfma_conv1_per_cell);
+/* Measurement aid: which conv/fc kernels sv_cnn_forward_* / sv_frames_to_digits launch in this process (SV_CONV_ALGO environment
+ * variable; default 4 = f16 hi/lo operand pairs on the f16 matrix pipe, csrc/k3_cnn_h2.hip) and the matrix instructions they
+ * issue per 28x28 cell: v_mfma_f32_16x16x4_f32 (2048 FLOP each) for conv2 and conv1 (0 = conv1 on the VALU) of the f32-MFMA
+ * kernels, or v_mfma_f32_16x16x32_f16 (16384 FLOP each) for the conv kernel and the fc kernel of the default pair.  bench.py prices
+ * a kernel's roofline fraction on the work it issues against the peak of the pipe it issues it on. */
+int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_f32_conv2_per_cell, int *mfma_f32_conv1_per_cell,
+                        int *mfma_f16_conv_per_cell, int *mfma_f16_fc_per_cell);
 
 /* Loads DigitCNN weights: `blob` [host] is the state_dict flattened in key order
  * conv1.weight[32,1,3,3] conv1.bias[32] conv2.weight[64,32,3,3] conv2.bias[64] fc1.weight[128,3136]

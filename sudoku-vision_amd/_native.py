@@ -22,7 +22,7 @@ SIGNATURES = {
     "sv_load_weights_f32": [_p, _p],
     "sv_timing_begin": [_p],
     "sv_timing_end": [_p, _p, _p],
-    "sv_conv_kernel_info": [_p, _p, _p, _p],
+    "sv_conv_kernel_info": [_p, _p, _p, _p, _p, _p],
     "sv_gray_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
     "sv_blur_u8": [_p, _p, _i, _i, _i, _i, _p, _p],
     "sv_adaptive_threshold_u8": [_p, _p, _i, _i, _i, _i, _d, _i, _p, _p],

@@ -1008,23 +1008,28 @@ int svk_softmax_topk(const float *logits, long B, int k, u8 *index, float *prob,
     return SV_OK;
 }
 
-// cross-check aid: 0 = direct implicit GEMM (k_conv_features_pc), 2 = Winograd stream on f32 MFMA (default), 3 = Winograd stream on
-// bf16 MFMA with three-way operand splitting (k_conv_features_wsplit)
+// which conv/fc kernels run: 4 = f16 hi/lo operand pairs on the f16 matrix pipe (k3_cnn_h2.hip, default); the f32-MFMA forms stay
+// selectable as cross-checks: 2 = Winograd stream, 0 = direct implicit GEMM (k_conv_features_pc); 3 = Winograd stream on bf16 MFMA
+// with three-way operand splitting (k_conv_features_wsplit)
 static int conv_algo_env()
 {
-    static const int algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 2;
+    static const int algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 4;
     return algo;
 }
 
-extern "C" int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_conv2_per_cell, int *mfma_conv1_per_cell)
+extern "C" int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_f32_conv2_per_cell, int *mfma_f32_conv1_per_cell, int *mfma_f16_conv_per_cell,
+                                   int *mfma_f16_fc_per_cell)
 {
-    if (!ctx || !algo || !mfma_conv2_per_cell || !mfma_conv1_per_cell) return sv_fail(SV_ERR_BAD_ARG, "sv_conv_kernel_info: NULL argument");
+    if (!ctx || !algo || !mfma_f32_conv2_per_cell || !mfma_f32_conv1_per_cell || !mfma_f16_conv_per_cell || !mfma_f16_fc_per_cell)
+        return sv_fail(SV_ERR_BAD_ARG, "sv_conv_kernel_info: NULL argument");
     const int a = conv_algo_env();
-    *algo = (a == 2 || a == 3) ? a : 0;
-    // Winograd: 49 tiles x 16 xi x 8 k-steps x 4 N tiles / 16 tiles per M tile; direct: 196 positions / 16 x 72 k-steps x 4 N tiles
-    // (the bf16-split kernel's MFMAs are bf16 ones: reported as 0 f32 MFMAs)
-    *mfma_conv2_per_cell = a == 2 ? 1568 : (a == 3 ? 0 : 3600);
-    *mfma_conv1_per_cell = 0;
+    *algo = (a == 2 || a == 3 || a == 4) ? a : 0;
+    // f32 Winograd: 49 tiles x 16 xi x 8 k-steps x 4 N tiles / 16 tiles per M tile; f32 direct: 196 positions / 16 x 72 k-steps x 4 N tiles
+    *mfma_f32_conv2_per_cell = a == 2 ? 1568 : ((a == 3 || a == 4) ? 0 : 3600);
+    *mfma_f32_conv1_per_cell = 0;
+    // f16 pairs: conv2 13 M tiles x 9 taps x 4 N tiles x 3 products + conv1 13 M tiles x 8 N tiles x 2; fc1 98 k-steps x 8 N tiles x 3 per 16 cells
+    *mfma_f16_conv_per_cell = a == 4 ? 13 * 9 * 4 * 3 + 13 * 8 * 2 : 0;
+    *mfma_f16_fc_per_cell = a == 4 ? 98 * 8 * 3 / 16 : 0;
     return SV_OK;
 }
 
@@ -1038,6 +1043,8 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
         x = ctx->cells2;
     }
     const int conv_algo = conv_algo_env();
+    // (the kernels that read 8-bit cells as dwords need a 4-byte-aligned buffer; a misaligned one takes the direct f32 kernel)
+    if (conv_algo == 4 && !(x_is_u8 && ((uintptr_t)x & 3))) return svk_cnn_forward_h2(ctx, x, x_is_u8, B, logits, digits, conf, s);
     if (conv_algo == 3 && ((uintptr_t)x & 3) == 0) {
         long cpw = (B + ctx->num_cus - 1) / ctx->num_cus;
         if (cpw < 1) cpw = 1;

@@ -1,0 +1,442 @@
+// K3, the default f32-accuracy form: DigitCNN.forward (ml/model.py:34-42) with conv2 and fc1 on the f16 matrix pipe.
+//
+// Why not the f32 MFMA: on gfx950 v_mfma_f32_16x16x4_f32 runs at the f32 VALU's rate (157 TF) and blocks the SIMD's VALU
+// issue while it runs (profiles/r01_ubench_mfma_valu_coexec.txt), so an f32 forward is bounded by the sum of its matrix and
+// vector work.  v_mfma_f32_16x16x32_f16 does 16x the work per cycle and co-issues with VALU work.  Each f32 operand x is
+// therefore carried as an unevaluated sum of two halves,  x ~= hi + lo,  hi = f16(x), lo = f16(x - hi)  (22 significant bits;
+// weights are pre-scaled by a power of two so that lo stays a normal f16), and a product a*w becomes the three partial
+// products  ah*wh + ah*wl + al*wh  accumulated in f32 by the MFMA (f16 x f16 products are exact in f32; the dropped al*wl
+// is < 2^-22 of the product).  What this does to the logits, measured against an exact (f64) evaluation of the same model on
+// the golden inputs: max error 1e-6, the same as PyTorch-CPU's own f32 forward (1.4e-6) -- tests/test_oracle_cnn.py holds the
+// simulation, tests/test_gpu_parity.py the measured kernel (<= 1e-4 is the contract, ~1e-6 is what comes out).
+// conv1, bias, ReLU, pooling, fc2 and the softmax stay in f32 on the VALU.
+//
+//   k_conv_features_h2 : persistent, one 512-thread workgroup per CU, producer waves (conv1 on the VALU) and consumer waves
+//        (conv2 on the matrix pipe) software-pipelined over cells with one barrier per cell; a producer and a consumer share
+//        each SIMD.  conv1 (f32 FMAs, a thread = one pooled pixel x 4 channels) writes its
+//        ReLU/pool output split into two f16 planes, channel-last (position-major, 32 channels = 64 B per position, rows padded
+//        against bank conflicts): one ds_read_b128 = one MFMA A operand (8 input channels of one 3x3 tap at one output
+//        position).  conv2 as an implicit GEMM: M = 4 pooling windows x 4 positions (so that the 4 accumulator registers of a
+//        lane are one pooling window: bias + ReLU + max never leave the lane), N = 2 x 16 channels per wave, K = 9 taps x 32
+//        channels; 3 MFMAs per (tap, N tile).  A wave keeps its 9 x 2 x 2 B operands in 144 VGPRs.
+//   k_fc_head_h2 : fc1 (3136 -> 128) with cells as M (one 16-cell tile per wave, 64 cells per workgroup); the 3.2 MB weight
+//        image (hi and lo halves) is staged once per workgroup through double-buffered LDS, features are read as f32 from
+//        global memory and split in registers; fc2 + argmax + softmax[argmax] epilogue in f32 (pipeline/run.py:139-143).
+//
+// The pure f32-MFMA kernels (k3_cnn.hip) remain selectable (SV_CONV_ALGO=2 / 0) and are what tests compare this file with.
+#include "sv_device.h"
+#include "sv_internal.h"
+#include <cstdlib>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+// One f16 plane of a cell: 16x16 zero-bordered positions, 32 channels = 64 B per position, 32 B of padding per row of 16
+// positions.  With these strides the 16 lanes of every ds_read_b128 lane group of an MFMA A-operand fetch (4 pooling windows x
+// 2x2 positions x 2 of the 4 k-groups) fall on 16 different 16-byte bank slots unless the tile's windows wrap to the next row
+// of the 7x7 grid (1.46 LDS cycles per group on average; the 80-B-per-position layout of the bf16 kernel is 4-way conflicted:
+// its two pooling-window rows are 1280 B apart, a multiple of the 256-B bank row).
+constexpr int POS_STRIDE = 64, ROW_STRIDE = 16 * POS_STRIDE + 32;
+constexpr int PLANE_B = 16 * ROW_STRIDE;
+constexpr int IN_PLANE_B = 32 * 64;             // one f16 plane of a cell's input: 30x30 zero-bordered pixels in 32 rows of 64 B
+constexpr int FEAT = 3136;
+
+__device__ __forceinline__ float glue_norm(u8 c)
+{
+    // x = ((255 - cell)/255 - 0.5)/0.5, one rounding per operation (pipeline/run.py:129-135)
+    const float t = __fdiv_rn((float)(255 - (int)c), 255.0f);
+    return __fdiv_rn(__fsub_rn(t, 0.5f), 0.5f);
+}
+
+// The compiler puts the s_waitcnt for a value loaded before a loop at its first use INSIDE the loop, where it then also waits, every
+// iteration, for whatever the loop itself has in flight (the next cell's input load, the previous tile's feature stores).  Touching the
+// registers in an empty asm statement ahead of the loop makes it wait there, once.
+__device__ __forceinline__ void settle(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void settle(float &v) { asm volatile("" : "+v"(v)); }
+
+__device__ __forceinline__ unsigned pack2h(_Float16 a, _Float16 b)
+{
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// v -> (hi, lo) with hi + lo = v to 22 bits
+__device__ __forceinline__ void split_h2(float v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// Persistent, one 512-thread workgroup per CU, two roles with one barrier per cell (register liveness stays within a role: the
+// 144 B-operand registers are never live in conv1 code, nor the conv1 weights in conv2 code):
+//   waves 4-7 (producers): conv1 of cell k on the VALU into c1[k & 1]; input of cell k+1 (loaded into registers at the top
+//                          of the step, written to LDS at its end)
+//   waves 0-3 (consumers): conv2 of cell k-1 from c1[(k-1) & 1] on the f16 matrix pipe (wave = N half x M-tile parity)
+// A consumer and a producer share each SIMD: f16 MFMAs co-issue with the other wave's VALU work.
+template <bool U8IN>
+__global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restrict__ xin, long B, const uint4 *__restrict__ w1img,
+                                                             const float *__restrict__ b1, float scale1_inv, const uint4 *__restrict__ w2img,
+                                                             const float *__restrict__ b2, float scale_inv, float *__restrict__ feat, int ablate)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char c1[2][2 * PLANE_B];  // [cell parity][part hi/lo][position][32 ch f16 + pad]
+    __shared__ __attribute__((aligned(16))) unsigned char inh[2][2][IN_PLANE_B]; // input [slot][part hi/lo][32 rows][32 f16], zero border
+    __shared__ __attribute__((aligned(8))) unsigned short lut_in[208], lut_out[208];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int c16 = lane & 15, q = lane >> 4;
+
+    for (int i = tid; i < 4 * PLANE_B / 4; i += 512) ((unsigned *)c1)[i] = 0;   // zero borders, for good
+    for (int i = tid; i < 4 * IN_PLANE_B / 4; i += 512) ((unsigned *)inh)[i] = 0;
+    for (int g = tid; g < 208; g += 512) {                                      // pooled pixel g of conv1 (13 tiles of 16; 196 real)
+        const int gc = g < 196 ? g : 195, wy = gc / 14, wx = gc - 14 * wy;
+        lut_in[g] = (unsigned short)((2 * wy) * 64 + 4 * wx);                   // its 4x4 input patch in an input plane
+        lut_out[g] = (unsigned short)((wy + 1) * ROW_STRIDE + (wx + 1) * POS_STRIDE);   // its position in a c1 plane (g > 195: pixel 195 again)
+    }
+    __syncthreads();
+
+    const long first = blockIdx.x, stride = gridDim.x;
+    const long ncell = first < B ? (B - first + stride - 1) / stride : 0;       // cells first, first + stride, ...
+    if (ncell == 0) return;
+
+    if (!consumer) {
+        const int ptid = tid & 255;
+        // Input of a cell -> inh[slot]: one dword (4 pixels of a row) per thread for 8-bit cells, up to 4 floats for f32 input;
+        // every value is split into its f16 pair on the way (pixel (y, x) sits at row y + 1, column x + 1 of a 64-byte row)
+        unsigned sraw[4] = {0, 0, 0, 0};
+        auto stage_load = [&](long c) {
+            if (U8IN) {
+                if (ptid < 196) sraw[0] = ((const unsigned *)((const u8 *)xin + c * 784))[ptid];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (ptid + 256 * j < 784) sraw[j] = __float_as_uint(((const float *)xin)[c * 784 + ptid + 256 * j]);
+            }
+        };
+        auto put = [&](int slot, int y, int x, float v) {
+            _Float16 h, l;
+            split_h2(v, h, l);
+            unsigned char *d = inh[slot][0] + (y + 1) * 64 + (x + 1) * 2;
+            *(_Float16 *)d = h;
+            *(_Float16 *)(d + IN_PLANE_B) = l;
+        };
+        auto stage_store = [&](int slot) {
+            if (U8IN) {
+                if (ptid < 196) {
+                    const int y = ptid / 7, x = 4 * (ptid - 7 * y);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) put(slot, y, x + j, glue_norm((u8)(sraw[0] >> (8 * j))));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i = ptid + 256 * j;
+                    if (i < 784) { const int y = i / 28; put(slot, y, i - y * 28, __uint_as_float(sraw[j])); }
+                }
+            }
+        };
+        // conv1 on the f16 matrix pipe too (as v_fma_f32 work it took 1330 VALU issue slots per wave per cell, and beside the
+        // consumers' MFMA stream a SIMD has only ~2 VALU slots per MFMA to give): rows = 16 pooling windows, K = the window's 4x4
+        // input patch twice -- k 0..15 from the hi plane, k 16..31 from the lo plane --, columns = 16 channels of one of the
+        // window's 4 conv positions (weights shifted accordingly, zero where a tap falls outside the 3x3).  Two MFMAs per
+        // (tile, position): [xh | xl] x [wh | wh]  and  [xh | xl] x [wl | 0].  The 4 positions are 4 accumulators of the same lane:
+        // max, scale, bias, ReLU in the lane; the result is split into its f16 pair and stored channel-last for conv2.
+        const int chalf = (wave >> 1) & 1, ppar = wave & 1;                     // this wave: channels 16*chalf.., M tiles ppar, ppar+2, ...
+        uint4 b1reg[4][2];
+#pragma unroll
+        for (int pos = 0; pos < 4; pos++)
+#pragma unroll
+            for (int m = 0; m < 2; m++) b1reg[pos][m] = w1img[((chalf * 4 + pos) * 2 + m) * 64 + lane];
+        float bias1 = b1[16 * chalf + c16];
+#pragma unroll
+        for (int pos = 0; pos < 4; pos++) { settle(b1reg[pos][0]); settle(b1reg[pos][1]); }
+        settle(bias1);
+        stage_load(first);
+        stage_store(0);
+        __syncthreads();                                                        // (A) input of cell 0 visible
+        // One producer wave per SIMD: nothing else hides its latencies, so the tile loop is software-pipelined by hand (tile jj's
+        // patch fetch and MFMAs are issued before tile jj-1's epilogue, accumulators double-buffered) and the window -> LDS offset
+        // arithmetic (divisions by 14) comes from two small tables.
+        const int ntile1 = (ablate & 1) ? 0 : (ppar ? 6 : 7);
+        for (long k = 0; k < ncell; k++) {
+            if (k + 1 < ncell) stage_load(first + (k + 1) * stride);            // lands while conv1 runs
+            const unsigned char *src_part = inh[k & 1][q >> 1] + 2 * (q & 1) * 64;   // this lane's plane (hi: k-groups 0,1; lo: 2,3) and patch rows
+            unsigned char *dst_cell = c1[k & 1] + (16 * chalf + c16) * 2;
+            f32x4 acc[2][4];
+            auto fetch_mfma = [&](int j, int set) {
+                const unsigned *src = (const unsigned *)(src_part + lut_in[16 * j + c16]);
+                const uint4 araw = {src[0], src[1], src[16], src[17]};          // patch rows 2(q&1), 2(q&1)+1: 4 halfs each
+                const h8 a = __builtin_bit_cast(h8, araw);
+#pragma unroll
+                for (int pos = 0; pos < 4; pos++) {
+                    acc[set][pos] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, b1reg[pos][0]), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acc[set][pos] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h8, b1reg[pos][1]), acc[set][pos], 0, 0, 0);
+                }
+            };
+            auto finish = [&](int j, int set) {
+                const uint2 oo = *(const uint2 *)&lut_out[16 * j + 4 * q];      // 4 x u16 store offsets of this lane's 4 pooled pixels
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {                             // rows 4q + reg = pooled pixels 16j + 4q + reg
+                    const float m = fmaxf(fmaxf(acc[set][0][reg], acc[set][1][reg]), fmaxf(acc[set][2][reg], acc[set][3][reg]));
+                    const float v = fmaxf(__builtin_fmaf(m, scale1_inv, bias1), 0.f);
+                    _Float16 h, l;
+                    split_h2(v, h, l);
+                    const unsigned off = ((reg & 2) ? oo.y : oo.x) >> (16 * (reg & 1)) & 0xFFFFu;
+                    *(_Float16 *)(dst_cell + off) = h;                          // (rows past pixel 195 recompute and rewrite pixel 195)
+                    *(_Float16 *)(dst_cell + off + PLANE_B) = l;
+                }
+            };
+            if (ntile1 > 0) fetch_mfma(ppar, 0);
+#pragma unroll
+            for (int jj = 1; jj < 7; jj++) {
+                if (jj >= ntile1) break;
+                fetch_mfma(ppar + 2 * jj, jj & 1);
+                finish(ppar + 2 * (jj - 1), (jj - 1) & 1);
+            }
+            if (ntile1 > 0) finish(ppar + 2 * (ntile1 - 1), (ntile1 - 1) & 1);
+            if (k + 1 < ncell) stage_store((k + 1) & 1);
+            __syncthreads();                                                    // (B_k) c1[k & 1] complete; consumers done with c1[(k-1) & 1]
+        }
+        __syncthreads();                                                        // (C) matches the consumers' last step
+        return;
+    }
+
+    const int np = wave >> 1, par = wave & 1;  // N half (channels 32np..32np+31), M-tile parity
+    uint4 breg[9][2][2];                       // [tap][t][part]: B[k = 8q+j][col c16] = W2s[oc = 32np + 2*c16 + t][ic = 8q + j][tap]
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) breg[tap][t][p] = w2img[(((tap * 2 + np) * 2 + t) * 2 + p) * 64 + lane];
+    float bias2_0 = b2[32 * np + 2 * c16], bias2_1 = b2[32 * np + 2 * c16 + 1];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) { settle(breg[tap][t][0]); settle(breg[tap][t][1]); }
+    settle(bias2_0);
+    settle(bias2_1);
+    __syncthreads();                                                            // (A)
+    __syncthreads();                                                            // (B_0)
+    // A consumer is alone on its SIMD's matrix pipe, so every cycle it spends outside MFMAs is idle pipe time (measured: 55 % idle
+    // with a plain tile loop).  Two measures, both relying on the tile loop being fully unrolled (all indices static):
+    //   * A operands flow through an RING-slot register ring filled PF steps (taps) ahead of their MFMAs, across tile boundaries;
+    //     in straight-line code the compiler counts its lgkmcnt waits exactly;
+    //   * accumulators are double-buffered by tile parity and the epilogue of tile j-1 (sum of the two accumulator sets, 2x2 max,
+    //     scale, bias, ReLU, store) is issued in four pieces between the MFMAs of taps 1-4 of tile j.
+    constexpr int PF = 4, RING = 5;
+    uint4 ring_h[RING], ring_l[RING];
+    int lane_off = (c16 >> 2) + 64 * ((c16 >> 1) & 1) + 128 * (c16 & 1) + 256 * q;   // window-in-tile | dy | dx | k-group
+    auto tile_base = [&](int buf, int j) -> const unsigned char * {
+        int g = 4 * j + (lane_off & 3);
+        if (g > 48) g = 48;
+        const int wy = g / 7, wx = g - 7 * wy;
+        return c1[buf] + (2 * wy + ((lane_off >> 6) & 1)) * ROW_STRIDE + (2 * wx + ((lane_off >> 7) & 1)) * POS_STRIDE + (lane_off >> 8) * 16;
+    };
+#define SV_TAP_OFF(tap) (((tap) / 3) * ROW_STRIDE + ((tap) % 3) * POS_STRIDE)
+    const int ntile = (ablate & 2) ? 0 : (par ? 6 : 7);
+    const unsigned out_off = 32 * np + 2 * c16;
+    for (long k = 0; k < ncell; k++) {
+        // (the per-tile LDS addresses are recomputed every cell -- a dozen VALU instructions per tile beside 54 MFMAs -- instead of
+        // living in 14 registers across the loop: with the 144 B-operand registers this kernel has none to spare)
+        asm volatile("" : "+v"(lane_off));
+        float *fcell = feat + (first + k * stride) * FEAT;                      // wave-uniform: scalar base + 32-bit lane offsets
+        const unsigned char *ap = tile_base((int)(k & 1), par);
+#pragma unroll
+        for (int st = 0; st < PF; st++) {                                       // the first tile of a cell cannot be fetched before the barrier
+            ring_h[st % RING] = *(const uint4 *)(ap + SV_TAP_OFF(st));
+            ring_l[st % RING] = *(const uint4 *)(ap + SV_TAP_OFF(st) + PLANE_B);
+        }
+        f32x4 acc_h[2][2], acc_l[2][2];                                         // [tile parity][t]
+        float y[2];
+        auto epilogue = [&](int piece, int pj, int set) {                       // tile pj, whose sums sit in accumulator set `set`
+            const int gw = 4 * pj + q;                                          // rows 4q..4q+3 = the 4 positions of window gw
+            if (piece < 2) {
+                const f32x4 v = acc_h[set][piece] + acc_l[set][piece];
+                y[piece] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) * scale_inv;
+            } else if (piece == 2) {
+                y[0] = fmaxf(y[0] + bias2_0, 0.f);
+                y[1] = fmaxf(y[1] + bias2_1, 0.f);
+            } else if (gw < 49) {
+                const unsigned boff = (out_off + (unsigned)gw * 64u) * 4u;         // 32-bit lane offset on a scalar base
+                *(f32x2 *)((char *)fcell + boff) = (f32x2){y[0], y[1]};
+            }
+        };
+        // 13 M tiles of 4 pooling windows; this wave takes tiles par, par+2, ... for its 32 channels
+#pragma unroll
+        for (int jj = 0; jj < 7; jj++) {
+            if (jj >= ntile) break;
+            const int j = par + 2 * jj, set = jj & 1;
+            const unsigned char *ap_next = tile_base((int)(k & 1), j + 2 < 13 ? j + 2 : j);
+#pragma unroll
+            for (int t = 0; t < 2; t++) { acc_h[set][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc_l[set][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int st = jj * 9 + tap;                                    // step number within the cell
+                if (tap + PF < 9) {
+                    ring_h[(st + PF) % RING] = *(const uint4 *)(ap + SV_TAP_OFF(tap + PF));
+                    ring_l[(st + PF) % RING] = *(const uint4 *)(ap + SV_TAP_OFF(tap + PF) + PLANE_B);
+                } else if (jj + 1 < ntile) {
+                    ring_h[(st + PF) % RING] = *(const uint4 *)(ap_next + SV_TAP_OFF(tap + PF - 9));
+                    ring_l[(st + PF) % RING] = *(const uint4 *)(ap_next + SV_TAP_OFF(tap + PF - 9) + PLANE_B);
+                }
+                __builtin_amdgcn_sched_barrier(0);                              // keep the fetch ahead of this tap's MFMAs
+                const h8 ah = __builtin_bit_cast(h8, ring_h[st % RING]), al = __builtin_bit_cast(h8, ring_l[st % RING]);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const h8 bh = __builtin_bit_cast(h8, breg[tap][t][0]), bl = __builtin_bit_cast(h8, breg[tap][t][1]);
+                    acc_h[set][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc_h[set][t], 0, 0, 0);
+                    acc_l[set][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_l[set][t], 0, 0, 0);
+                    acc_l[set][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_l[set][t], 0, 0, 0);
+                }
+                if (jj > 0 && tap >= 1 && tap <= 4) epilogue(tap - 1, j - 2, set ^ 1);
+            }
+            ap = ap_next;
+        }
+        if (ntile > 0) {
+            const int jl = par + 2 * (ntile - 1), setl = (ntile - 1) & 1;
+#pragma unroll
+            for (int piece = 0; piece < 4; piece++) epilogue(piece, jl, setl);
+        }
+        __syncthreads();                                                        // (B_{k+1}) / (C)
+    }
+#undef SV_TAP_OFF
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_fc_head_h2: 64 cells per 256-thread workgroup, one 16-cell M tile per wave, all 8 N tiles (128 hidden units).
+// K = 3136 in 98 steps of 32; a stage = 2 steps of the weight image (2 x 8 N tiles x hi/lo x 1 KB = 32 KB), global ->
+// registers -> LDS, double-buffered, one barrier per stage.  A: 16 consecutive f32 features per lane per stage straight from
+// global memory (four dwordx4, issued a stage ahead), split into hi/lo in registers.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__ feat, long B, const uint4 *__restrict__ w1img,
+                                                       const float *__restrict__ b1, float scale_inv, const float *__restrict__ w2,
+                                                       const float *__restrict__ b2, float *__restrict__ logits,
+                                                       u8 *__restrict__ digits, float *__restrict__ conf)
+{
+    constexpr int SPS = 2, STAGE_V = SPS * 8 * 2 * 64, NSTAGE = 98 / SPS, WPT = STAGE_V / 256;   // uint4 per stage, per thread
+    __shared__ __attribute__((aligned(16))) uint4 wt[2][STAGE_V];    // 2 x 32 KB; the hidden activations alias it after the K loop
+    __shared__ float w2s[10][128];
+    __shared__ float lg[4][16][12];
+    float(*hs)[16][129] = (float(*)[16][129])wt;                      // [4][16][129] floats = 33 KB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const long cell0 = (long)blockIdx.x * 64 + wave * 16;
+    long crow = cell0 + r;
+    if (crow >= B) crow = B - 1;
+    // K is permuted so that a lane's operands of the SPS = 2 steps of a stage are 16 consecutive floats (k-slot (q, j) of step
+    // 2S + ss = feature 64S + 16q + 8ss + j; the weight image is packed to match): the four q-lanes of a row read 256
+    // contiguous bytes per stage instead of four 32-byte pieces per step
+    const f32x4 *ap = (const f32x4 *)(feat + crow * FEAT + 16 * q);    // stage S: + 16*S float4
+
+    for (int i = tid; i < 1280; i += 256) w2s[i >> 7][i & 127] = w2[i];
+
+    f32x4 acc_h[8], acc_l[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) { acc_h[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc_l[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    uint4 wreg[WPT];
+    f32x4 areg[SPS][2];
+#pragma unroll
+    for (int j = 0; j < WPT; j++) wreg[j] = w1img[256 * j + tid];
+#pragma unroll
+    for (int s = 0; s < SPS; s++) { areg[s][0] = ap[2 * s]; areg[s][1] = ap[2 * s + 1]; }
+#pragma unroll
+    for (int j = 0; j < WPT; j++) wt[0][256 * j + tid] = wreg[j];
+    __syncthreads();
+
+    for (int st = 0; st < NSTAGE; st++) {
+        const int cur = st & 1;
+        f32x4 a[SPS][2];
+#pragma unroll
+        for (int s = 0; s < SPS; s++) { a[s][0] = areg[s][0]; a[s][1] = areg[s][1]; }
+        if (st + 1 < NSTAGE) {                                        // next stage: global -> registers while this one computes
+#pragma unroll
+            for (int j = 0; j < WPT; j++) wreg[j] = w1img[(long)(st + 1) * STAGE_V + 256 * j + tid];
+#pragma unroll
+            for (int s = 0; s < SPS; s++) { areg[s][0] = ap[16 * (st + 1) + 2 * s]; areg[s][1] = ap[16 * (st + 1) + 2 * s + 1]; }
+        }
+#pragma unroll
+        for (int s = 0; s < SPS; s++) {
+            _Float16 h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { split_h2(a[s][0][e], h[e], l[e]); split_h2(a[s][1][e], h[4 + e], l[4 + e]); }
+            const h8 ah = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]}, al = {l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const h8 bh = __builtin_bit_cast(h8, wt[cur][((s * 8 + t) * 2 + 0) * 64 + lane]);
+                const h8 bl = __builtin_bit_cast(h8, wt[cur][((s * 8 + t) * 2 + 1) * 64 + lane]);
+                acc_h[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc_h[t], 0, 0, 0);
+                acc_l[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_l[t], 0, 0, 0);
+                acc_l[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_l[t], 0, 0, 0);
+            }
+        }
+        if (st + 1 < NSTAGE) {
+#pragma unroll
+            for (int j = 0; j < WPT; j++) wt[cur ^ 1][256 * j + tid] = wreg[j];
+        }
+        __syncthreads();
+    }
+
+    // acc[t][reg]: cell row 4q + reg of this wave's tile, hidden unit 16t + r   (hs aliases the weight stages: all waves are
+    // past the last barrier of the K loop, nobody reads wt any more)
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float bias = b1[16 * t + r];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) hs[wave][4 * q + reg][16 * t + r] = fmaxf((acc_h[t][reg] + acc_l[t][reg]) * scale_inv + bias, 0.f);
+    }
+    __syncthreads();
+    for (int jj = 0; jj < 3; jj++) {                                  // fc2: lane (cell r, class group q) -> classes q, q+4, q+8
+        const int j = q + 4 * jj;
+        if (j < 10) {
+            float s = b2[j];
+            for (int n = 0; n < 128; n++) s = __builtin_fmaf(hs[wave][r][n], w2s[j][n], s);
+            lg[wave][r][j] = s;
+            if (cell0 + r < B) logits[(cell0 + r) * 10 + j] = s;
+        }
+    }
+    __syncthreads();
+    if (q == 0 && cell0 + r < B && (digits || conf)) {
+        float best = lg[wave][r][0];
+        int arg = 0;
+        for (int j = 1; j < 10; j++)
+            if (lg[wave][r][j] > best) { best = lg[wave][r][j]; arg = j; }
+        if (digits) digits[cell0 + r] = (u8)arg;
+        if (conf) {
+            float den = 0.f;
+            for (int j = 0; j < 10; j++) den += expf(lg[wave][r][j] - best);
+            conf[cell0 + r] = 1.0f / den;
+        }
+    }
+}
+
+}  // namespace
+
+int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
+{
+    const sv_weights &w = ctx->w;
+    const int grid = (int)(B < (long)ctx->num_cus ? B : (long)ctx->num_cus);
+    // tuning aid (wrong results): SV_H2_ABLATE bit 0 skips the producers' conv1 tiles, bit 1 the consumers' conv2 tiles
+    static const int ablate = getenv("SV_H2_ABLATE") ? atoi(getenv("SV_H2_ABLATE")) : 0;
+    {
+        sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
+        if (x_is_u8)
+            hipLaunchKernelGGL(k_conv_features_h2<true>, dim3(grid), dim3(512), 0, s, x, B, (const uint4 *)w.conv1_h2, w.conv1_b, w.conv1_h2_scale_inv, (const uint4 *)w.conv2_h2, w.conv2_b,
+                               w.conv2_h2_scale_inv, ctx->features, ablate);
+        else
+            hipLaunchKernelGGL(k_conv_features_h2<false>, dim3(grid), dim3(512), 0, s, x, B, (const uint4 *)w.conv1_h2, w.conv1_b, w.conv1_h2_scale_inv, (const uint4 *)w.conv2_h2, w.conv2_b,
+                               w.conv2_h2_scale_inv, ctx->features, ablate);
+    }
+    SV_LAUNCH_CHECK("k_conv_features_h2");
+    sv_time_scope ts(ctx, SVK_FC_HEAD, s);
+    hipLaunchKernelGGL(k_fc_head_h2, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, ctx->features, B, (const uint4 *)w.fc1_h2, w.fc1_b, w.fc1_h2_scale_inv,
+                       w.fc2_w, w.fc2_b, logits, digits, conf);
+    SV_LAUNCH_CHECK("k_fc_head_h2");
+    return SV_OK;
+}

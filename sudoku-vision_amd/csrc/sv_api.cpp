@@ -51,6 +51,11 @@ static void free_weights(sv_weights &w)
     if (w.conv2_bf16) (void)hipFree(w.conv2_bf16);
     if (w.fc1_bf16) (void)hipFree(w.fc1_bf16);
     w.conv2_bf16 = w.fc1_bf16 = nullptr;
+    if (w.conv1_h2) (void)hipFree(w.conv1_h2);
+    w.conv1_h2 = nullptr;
+    if (w.conv2_h2) (void)hipFree(w.conv2_h2);
+    if (w.fc1_h2) (void)hipFree(w.fc1_h2);
+    w.conv2_h2 = w.fc1_h2 = nullptr;
     w.loaded = false;
 }
 
@@ -231,6 +236,69 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
                     const int kp = 32 * st + 8 * (lane >> 4) + j, win = kp >> 6, oc = kp & 63, n = 16 * t + (lane & 15);
                     fc1b[(((size_t)st * 8 + t) * 64 + lane) * 8 + j] = bf16(f1w[(size_t)n * 3136 + oc * 49 + win]);
                 }
+    // k3_cnn_h2.hip: w * 2^e = hi + lo, both f16 (round to nearest), e chosen so that max|w| * 2^e lies in [2^13, 2^14): hi is far
+    // from f16's overflow (65504) and lo (~2^-11 of hi) stays a normal f16 for all but the tiniest weights
+    auto pow2_scale = [](const float *v, size_t n) -> int {
+        float m = 0.f;
+        for (size_t i = 0; i < n; i++) m = std::fmax(m, std::fabs(v[i]));
+        if (!(m > 0.f) || !std::isfinite(m)) return 0;
+        const int e = 13 - std::ilogb(m);
+        return e < -14 ? -14 : (e > 40 ? 40 : e);
+    };
+    auto split_h2 = [](float ws, uint16_t &hi, uint16_t &lo) {
+        const _Float16 h = (_Float16)ws;
+        const _Float16 l = (_Float16)(ws - (float)h);
+        memcpy(&hi, &h, 2);
+        memcpy(&lo, &l, 2);
+    };
+    const int e2 = pow2_scale(c2w, 18432), e1 = pow2_scale(f1w, 401408);
+    const float s2 = std::ldexp(1.f, e2), s1 = std::ldexp(1.f, e1);
+    ctx->w.conv2_h2_scale_inv = std::ldexp(1.f, -e2);
+    ctx->w.fc1_h2_scale_inv = std::ldexp(1.f, -e1);
+    std::vector<uint16_t> c2h((size_t)9 * 2 * 2 * 2 * 64 * 8), f1h((size_t)98 * 8 * 2 * 64 * 8);
+    for (int tap = 0; tap < 9; tap++)
+        for (int np = 0; np < 2; np++)
+            for (int t = 0; t < 2; t++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int oc = 32 * np + 2 * (lane & 15) + t, ic = 8 * (lane >> 4) + j;
+                        const size_t base = ((((size_t)tap * 2 + np) * 2 + t) * 2) * 64 * 8;
+                        split_h2(c2w[(oc * 32 + ic) * 9 + tap] * s2, c2h[base + (size_t)lane * 8 + j], c2h[base + 512 + (size_t)lane * 8 + j]);
+                    }
+    for (int st = 0; st < 98; st++)
+        for (int t = 0; t < 8; t++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    // k-slot (q, j) of step st = feature 64*(st/2) + 16q + 8*(st%2) + j: a lane's operands of a 2-step stage are contiguous
+                    const int kp = 64 * (st >> 1) + 16 * (lane >> 4) + 8 * (st & 1) + j, win = kp >> 6, oc = kp & 63, n = 16 * t + (lane & 15);
+                    const size_t base = (((size_t)st * 8 + t) * 2) * 64 * 8;
+                    split_h2(f1w[(size_t)n * 3136 + oc * 49 + win] * s1, f1h[base + (size_t)lane * 8 + j], f1h[base + 512 + (size_t)lane * 8 + j]);
+                }
+    // conv1 as a GEMM over the 4x4 input patch of a pooling window: k = 16*part + 4r + c (part 0: hi plane of the input, 1: lo plane),
+    // column = channel 16*chalf + (lane&15) at conv position (dy, dx) of the window; B = w1[ch][r-dy][c-dx] (0 outside the 3x3).
+    // MFMA 0 multiplies [xh | xl] by [wh | wh], MFMA 1 by [wl | 0]:  xh*wh + xl*wh + xh*wl.
+    const int e0 = pow2_scale(c1w, 288);
+    const float s0 = std::ldexp(1.f, e0);
+    ctx->w.conv1_h2_scale_inv = std::ldexp(1.f, -e0);
+    std::vector<uint16_t> c1h((size_t)2 * 4 * 2 * 64 * 8);
+    for (int chalf = 0; chalf < 2; chalf++)
+        for (int pos = 0; pos < 4; pos++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int kk = 8 * (lane >> 4) + j, part = kk >> 4, pp = kk & 15, r = pp >> 2, c = pp & 3;
+                    const int ky = r - (pos >> 1), kx = c - (pos & 1), ch = 16 * chalf + (lane & 15);
+                    uint16_t hi = 0, lo = 0;
+                    if (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) split_h2(c1w[ch * 9 + ky * 3 + kx] * s0, hi, lo);
+                    const size_t base = (((size_t)chalf * 4 + pos) * 2) * 64 * 8 + (size_t)lane * 8 + j;
+                    c1h[base] = hi;
+                    c1h[base + 512] = part == 0 ? lo : 0;
+                }
+    SV_HIP(hipMalloc((void **)&ctx->w.conv1_h2, c1h.size() * 2));
+    SV_HIP(hipMemcpy(ctx->w.conv1_h2, c1h.data(), c1h.size() * 2, hipMemcpyHostToDevice));
+    SV_HIP(hipMalloc((void **)&ctx->w.conv2_h2, c2h.size() * 2));
+    SV_HIP(hipMemcpy(ctx->w.conv2_h2, c2h.data(), c2h.size() * 2, hipMemcpyHostToDevice));
+    SV_HIP(hipMalloc((void **)&ctx->w.fc1_h2, f1h.size() * 2));
+    SV_HIP(hipMemcpy(ctx->w.fc1_h2, f1h.data(), f1h.size() * 2, hipMemcpyHostToDevice));
     SV_HIP(hipMalloc((void **)&ctx->w.conv2_wsplit, wsplit.size() * 2));
     SV_HIP(hipMemcpy(ctx->w.conv2_wsplit, wsplit.data(), wsplit.size() * 2, hipMemcpyHostToDevice));
     SV_HIP(hipMalloc((void **)&ctx->w.conv2_bf16, w2b.size() * 2));

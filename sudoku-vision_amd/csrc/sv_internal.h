@@ -22,6 +22,11 @@ struct sv_weights {
     unsigned short *conv2_wsplit = nullptr; // [4 nt][16 xi][3 parts][64 lane][8] U split into three bf16 parts (k_conv_features_wsplit)
     unsigned short *conv2_bf16 = nullptr; // [9 tap][4 t][64 lane][8] bf16 MFMA B image (bf16 configuration)
     unsigned short *fc1_bf16 = nullptr;   // [98 step][8 t][64 lane][8] bf16
+    // k3_cnn_h2.hip: weights x 2^e split into f16 hi + lo (w * 2^e = hi + lo to 22 bits); scale_inv = 2^-e
+    unsigned short *conv2_h2 = nullptr;   // [9 tap][2 np][2 t][2 part][64 lane][8] f16: oc = 32np + 2*(lane&15) + t, ic = 8*(lane>>4) + j
+    unsigned short *fc1_h2 = nullptr;     // [98 step][8 t][2 part][64 lane][8] f16: n = 16t + (lane&15), feature = 64*(step/2) + 16*(lane>>4) + 8*(step%2) + j
+    unsigned short *conv1_h2 = nullptr;   // [2 chalf][4 pos][2 mfma][64 lane][8] f16: conv1 as a GEMM over the 4x4 patch of a pooling window (k3_cnn_h2.hip)
+    float conv1_h2_scale_inv = 1.f, conv2_h2_scale_inv = 1.f, fc1_h2_scale_inv = 1.f;
     float *fc2_w = nullptr;     // [10][128]
     float *fc2_b = nullptr;     // [10]
     bool loaded = false;
@@ -89,6 +94,7 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
 int svk_despeckle(const u8 *src, int n, int H, int W, u8 *dst, unsigned *packed, hipStream_t s);
 int svk_resize_linear(const u8 *src, int sh, int sw, ptrdiff_t pitch, u8 *dst, int dh, int dw, hipStream_t s);
 int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8 *digits, float *conf, hipStream_t s);
+int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, hipStream_t s);
 int svk_cell_ink_ratio(const u8 *cells, long B, int npx, float *ratio, int *otsu, hipStream_t s);
 int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s);
 int svk_jpeg_reconstruct(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint64_t *masks, const uint32_t *offsets, const int16_t *values,

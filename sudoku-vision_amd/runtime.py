@@ -98,14 +98,18 @@ class Context:
         _native.check(_native.lib().sv_timing_end(self._h, ms, cnt), "sv_timing_end")
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNELS)}
 
-    CONV_ALGO_NAMES = {0: "k_conv_features_pc (direct implicit GEMM, f32 MFMA)", 2: "k_conv_features_wstream (Winograd F(2x2,3x3), f32 MFMA)",
-                       3: "k_conv_features_wsplit (Winograd, bf16 MFMA with 3-way operand split)"}
+    CONV_ALGO_NAMES = {0: "k_conv_features_pc + k_fc_head_frame (direct implicit GEMM, f32 MFMA)",
+                       2: "k_conv_features_wstream + k_fc_head_frame (Winograd F(2x2,3x3), f32 MFMA)",
+                       3: "k_conv_features_wsplit + k_fc_head_frame (Winograd, bf16 MFMA with 3-way operand split)",
+                       4: "k_conv_features_h2 + k_fc_head_h2 (f16 hi/lo operand pairs, f16 MFMA, f32 accumulation)"}
 
     def conv_kernel_info(self):
-        """Which f32 conv kernel this process launches and the f32 MFMA instructions it issues per cell (sv_conv_kernel_info)."""
-        a, m2, m1 = C.c_int(), C.c_int(), C.c_int()
-        _native.check(_native.lib().sv_conv_kernel_info(self._h, C.byref(a), C.byref(m2), C.byref(m1)), "sv_conv_kernel_info")
-        return {"algo": a.value, "name": self.CONV_ALGO_NAMES.get(a.value, str(a.value)), "mfma_conv2": m2.value, "mfma_conv1": m1.value}
+        """Which conv/fc kernels this process launches and the matrix instructions they issue per cell (sv_conv_kernel_info)."""
+        v = [C.c_int() for _ in range(5)]
+        _native.check(_native.lib().sv_conv_kernel_info(self._h, *[C.byref(x) for x in v]), "sv_conv_kernel_info")
+        a = v[0].value
+        return {"algo": a, "name": self.CONV_ALGO_NAMES.get(a, str(a)), "mfma_conv2": v[1].value, "mfma_conv1": v[2].value,
+                "mfma_f16_conv": v[3].value, "mfma_f16_fc": v[4].value}
 
     # ---- K1 -----------------------------------------------------------------------------------
     def gray(self, bgr):

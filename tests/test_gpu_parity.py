@@ -400,8 +400,10 @@ def test_bf16_configuration_digit_parity(golden_dir):
 
 
 def test_conv_algorithms_agree(golden_dir):
-    """Three independent conv2 implementations -- Winograd stream on f32 MFMA (SV_CONV_ALGO=2), direct implicit GEMM (0) and the
-    Winograd stream on bf16 MFMA with three-way operand splitting (3) -- give the same logits to ~1e-5 and the same digits; run in
+    """Four independent conv2 (+ two fc1) implementations -- the default f16 hi/lo operand pairs on the f16 matrix pipe
+    (SV_CONV_ALGO=4, k3_cnn_h2.hip), Winograd stream on f32 MFMA (2), direct implicit GEMM on f32 MFMA (0) and the Winograd stream on
+    bf16 MFMA with three-way operand splitting (3) -- give the same logits to ~1e-5 and the same digits, and each is within 1e-4
+    of the PyTorch-CPU restatement (the default within 1e-5: its operand pairs carry 22 bits, its sums are f32); run in
     subprocesses because the choice is read once per process."""
     import subprocess
     import sys
@@ -414,13 +416,18 @@ def test_conv_algorithms_agree(golden_dir):
             "ctx = sva.default_context(); ctx.load_state_dict(sd)\n"
             "x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (500, 28, 28)).astype(np.uint8)).cuda()\n"
             "np.save(sys.argv[1], ctx.cnn_forward(x).cpu().numpy())\n")
+    g = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    cells = np.random.RandomState(1).randint(0, 256, (500, 28, 28)).astype(np.uint8)
+    want = cnn_oracle.forward(sd, o.cells_to_input(cells)[:, None]).numpy()
     outs = []
-    for algo in ("2", "0", "3"):
+    for algo in ("4", "2", "0", "3"):
         path = f"/tmp/sv_conv_algo_{algo}.npy"
         env = dict(os.environ, SV_CONV_ALGO=algo)
         r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(path))
+        assert np.abs(outs[-1] - want).max() <= (1e-5 if algo == "4" else LOGIT_TOL), algo
     for other in outs[1:]:
         assert np.abs(outs[0] - other).max() <= 2e-5
         assert (outs[0].argmax(1) == other.argmax(1)).all()

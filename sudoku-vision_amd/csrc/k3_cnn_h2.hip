@@ -19,7 +19,7 @@
 //        position).  conv2 as an implicit GEMM: M = 4 pooling windows x 4 positions (so that the 4 accumulator registers of a
 //        lane are one pooling window: bias + ReLU + max never leave the lane), N = 2 x 16 channels per wave, K = 9 taps x 32
 //        channels; 3 MFMAs per (tap, N tile).  A wave keeps its 9 x 2 x 2 B operands in 144 VGPRs.
-//   k_fc_head_h2 : fc1 (3136 -> 128) with cells as M (one 16-cell tile per wave, 64 cells per workgroup); the 3.2 MB weight
+//   k_fc_head_h2 : fc1 (3136 -> 128) with cells as M (one 16-cell tile per wave, 64 cells per workgroup); the 1.6 MB weight
 //        image (hi and lo halves) is staged once per workgroup through double-buffered LDS, features are read as f32 from
 //        global memory and split in registers; fc2 + argmax + softmax[argmax] epilogue in f32 (pipeline/run.py:139-143).
 //
@@ -307,7 +307,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_fc_head_h2: 64 cells per 256-thread workgroup, one 16-cell M tile per wave, all 8 N tiles (128 hidden units).
+// k_fc_head_h2: 64 cells per 256-thread workgroup, one 16-cell M tile per wave, all 8 N tiles (128 hidden units), two workgroups
+// per CU.  (Staging the 1.6 MB weight image through LDS is 3/4 of this kernel's time by ablation; a 96-cell, one-workgroup-per-CU
+// form with three LDS stages ran at half the speed: the kernel lives on the second workgroup hiding the staging latency.)
 // K = 3136 in 98 steps of 32; a stage = 2 steps of the weight image (2 x 8 N tiles x hi/lo x 1 KB = 32 KB), global ->
 // registers -> LDS, double-buffered, one barrier per stage.  A: 16 consecutive f32 features per lane per stage straight from
 // global memory (four dwordx4, issued a stage ahead), split into hi/lo in registers.
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__
 #pragma unroll
             for (int s = 0; s < SPS; s++) { areg[s][0] = ap[16 * (st + 1) + 2 * s]; areg[s][1] = ap[16 * (st + 1) + 2 * s + 1]; }
         }
+        __builtin_amdgcn_sched_barrier(0);     // (the compiler otherwise sinks these loads to their use at the end of the stage, exposing their latency)
 #pragma unroll
         for (int s = 0; s < SPS; s++) {
             _Float16 h[8], l[8];

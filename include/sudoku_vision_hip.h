@@ -152,6 +152,11 @@ int sv_find_contours_u8(const uint8_t *binary /*host*/, int H, int W, ptrdiff_t 
                         int *points /*host, cap_points*2*/, long cap_points, int *sizes /*host*/,
                         int cap_contours, long *n_points, int *n_contours);
 
+/* The same on a bit-packed image (1 bit per pixel, LSB = leftmost, W/32 words per row -- sv_despeckle_u8's packed output; W % 32 == 0):
+ * the scanner sv_find_grid_corners_bits_batch uses, which never expands the image to bytes.  Same contours, same order. */
+int sv_find_contours_bits(const uint32_t *bits /*host*/, int H, int W, int *points, long cap_points, int *sizes, int cap_contours,
+                          long *n_points, int *n_contours);
+
 /* cv2.contourArea / cv2.arcLength / cv2.approxPolyDP on int32 (x,y) vertices (cv/grid.py:31-33,58,61). */
 int sv_contour_area_i32(const int *xy /*host*/, int n, double *area);
 int sv_arc_length_i32(const int *xy /*host*/, int n, int closed, double *length);

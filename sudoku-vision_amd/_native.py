@@ -35,6 +35,7 @@ SIGNATURES = {
     "sv_find_grid_corners_u8": [_p, _i, _i, _pd, _d, _d, _p],
     "sv_find_grid_corners_batch_u8": [_p, _i, _i, _i, _pd, _pd, _d, _d, _p, _p, _i],
     "sv_find_contours_u8": [_p, _i, _i, _pd, _p, _l, _p, _i, _p, _p],
+    "sv_find_contours_bits": [_p, _i, _i, _p, _l, _p, _i, _p, _p],
     "sv_contour_area_i32": [_p, _i, _p],
     "sv_arc_length_i32": [_p, _i, _i, _p],
     "sv_approx_poly_dp_i32": [_p, _i, _d, _i, _p, _p],

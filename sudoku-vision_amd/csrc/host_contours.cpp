@@ -108,7 +108,18 @@ class BorderScanner {
                     p = row[x];
                 }
                 prev = p;
-                if (prev & ~1) last_marked = x;
+                if (prev & ~1) {
+                    last_marked = x;
+                    if (prev > 0) {
+                        // Inside a followed outer border (its mark here is positive): until the scan passes a right-exit mark
+                        // (negative) `last_marked` keeps pointing at a positive label and no border can start, whatever lies in
+                        // between -- the lines and digits inside the grid.  Go straight to the next negative label of the row.
+                        x = next_negative(row, x + 1);
+                        if (x > w_) break;
+                        prev = row[x];
+                        last_marked = x;
+                    }
+                }
                 x++;
             }
         }
@@ -128,6 +139,20 @@ class BorderScanner {
         for (k++; k < wpr_; k++)
             if (brow[k]) return 32 * k + __builtin_ctz(brow[k]) + 1;
         return w_ + 1;
+    }
+
+    // first x' >= x whose label is negative (a right-exit mark), or w_+1
+    int next_negative(const int8_t *row, int x) const
+    {
+        while (x + 8 <= w_ + 1) {
+            uint64_t v;
+            memcpy(&v, row + x, 8);
+            v &= 0x8080808080808080ull;
+            if (v) return x + (__builtin_ctzll(v) >> 3);
+            x += 8;
+        }
+        while (x <= w_ && row[x] >= 0) x++;
+        return x;
     }
 
     // first x' >= x with row[x'] != prev (or w_+1)
@@ -197,6 +222,154 @@ class BorderScanner {
     int wpr_ = 0;
     std::pair<int, int> *span_ = nullptr;
     int delta_[16];
+};
+
+// The same scan on a bit-packed image (1 bit per pixel, LSB = leftmost, W/32 words per row: sv_despeckle_u8's packed output), without
+// ever expanding it to bytes -- building and clearing a byte-per-pixel label image was half of the search's time.  A label is two
+// bits in two side planes: T = "this pixel is on a followed border", R = "... and the border leaves it to the right" (the byte
+// scanner's 2 and 0x82); an unlabelled set pixel is the byte scanner's 1.  The raster scan only ever has to look at the pixels
+// where its state can change: labelled pixels, and unlabelled pixels that start a run (set, left neighbour clear).  A border may
+// start at such a run start iff the last label passed on the row was a right-exit (or there was none); once a positive label has been
+// passed nothing can start before the next right-exit, so the scan jumps there -- the lines and digits inside a followed grid
+// border cost nothing.  Same borders, same points, same order as BorderScanner (tests/test_host_contours.py compares them).
+class BitScanner {
+  public:
+    BitScanner(const uint32_t *bits, int H, int W) : b_(bits), h_(H), w_(W), wpr_(W >> 5)
+    {
+        Planes &tl = planes();
+        const size_t words = (size_t)H * wpr_;
+        if (tl.t.size() != words) {
+            tl.t.assign(words, 0);
+            tl.r.assign(words, 0);
+            tl.dirty.assign((size_t)H, {0, 0});
+        } else {
+            for (int y = tl.y0; y <= tl.y1; y++) {                 // only the word spans the previous frame's borders touched
+                auto &d = tl.dirty[y];
+                if (d.second > d.first) {
+                    memset(tl.t.data() + (size_t)y * wpr_ + d.first, 0, (size_t)(d.second - d.first) * 4);
+                    memset(tl.r.data() + (size_t)y * wpr_ + d.first, 0, (size_t)(d.second - d.first) * 4);
+                }
+                d = {0, 0};
+            }
+        }
+        tl.y0 = H; tl.y1 = -1;
+        t_ = tl.t.data(); r_ = tl.r.data(); pl_ = &tl;
+    }
+
+    void run()
+    {
+        for (int y = 0; y < h_; y++) {
+            const uint32_t *brow = b_ + (size_t)y * wpr_;
+            const uint32_t *trow = t_ + (size_t)y * wpr_, *rrow = r_ + (size_t)y * wpr_;
+            bool inside = false;                                  // the last label passed on this row is positive
+            int x = 0;
+            for (;;) {
+                // next pixel >= x that is labelled or starts a run
+                int pos = -1;
+                {
+                    int k = x >> 5;
+                    if (k < wpr_) {                                // first word: only the bits from x on
+                        const uint32_t bw = brow[k];
+                        const uint32_t e = (trow[k] | (bw & ~((bw << 1) | (k ? brow[k - 1] >> 31 : 0u)))) & (~0u << (x & 31));
+                        if (e) pos = 32 * k + __builtin_ctz(e);
+                        else
+                            for (k++; k < wpr_; k++) {
+                                const uint32_t b2 = brow[k], t2 = trow[k];
+                                if (!(b2 | t2)) continue;          // most words of a despeckled frame are empty
+                                const uint32_t e2 = t2 | (b2 & ~((b2 << 1) | (brow[k - 1] >> 31)));
+                                if (e2) { pos = 32 * k + __builtin_ctz(e2); break; }
+                            }
+                    }
+                }
+                if (pos < 0) break;
+                const uint32_t m = 1u << (pos & 31);
+                if (!(trow[pos >> 5] & m)) {
+                    if (!inside) follow(pos, y);                  // labels (pos, y) among others
+                    else { x = pos + 1; continue; }               // (not reached: `inside` jumps below)
+                }
+                inside = !(rrow[pos >> 5] & m);
+                x = pos + 1;
+                if (inside) {                                     // nothing can start before the next right-exit label
+                    int nx = -1;
+                    for (int k = x >> 5; k < wpr_; k++) {
+                        uint32_t e = rrow[k];
+                        if (k == (x >> 5)) e &= ~0u << (x & 31);
+                        if (e) { nx = 32 * k + __builtin_ctz(e); break; }
+                    }
+                    if (nx < 0) break;
+                    inside = false;
+                    x = nx + 1;
+                }
+            }
+        }
+    }
+
+    std::vector<Pt> points;
+    std::vector<Contour> contours;  // in discovery order (cv2 reports them reversed)
+
+  private:
+    struct Planes { std::vector<uint32_t> t, r; std::vector<std::pair<int, int>> dirty; int y0 = 0, y1 = -1; };
+    static Planes &planes() { static thread_local Planes p; return p; }
+
+    inline bool set(int x, int y) const { return (unsigned)x < (unsigned)w_ && (unsigned)y < (unsigned)h_ && (b_[(size_t)y * wpr_ + (x >> 5)] >> (x & 31) & 1u); }
+    inline void touch(int x, int y)
+    {
+        auto &d = pl_->dirty[y];
+        const int k = x >> 5;
+        if (d.second == d.first) d = {k, k + 1};
+        else { if (k < d.first) d.first = k; if (k + 1 > d.second) d.second = k + 1; }
+        if (y < pl_->y0) pl_->y0 = y;
+        if (y > pl_->y1) pl_->y1 = y;
+    }
+    inline void mark_right(int x, int y) { touch(x, y); const size_t i = (size_t)y * wpr_ + (x >> 5); t_[i] |= 1u << (x & 31); r_[i] |= 1u << (x & 31); }
+    inline void mark_plain(int x, int y) { const size_t i = (size_t)y * wpr_ + (x >> 5); if (!(t_[i] >> (x & 31) & 1u)) { touch(x, y); t_[i] |= 1u << (x & 31); } }
+
+    // BorderScanner::follow on the bit planes (x, y are image coordinates here; the byte scanner's are the same minus its padding)
+    void follow(int sx, int sy)
+    {
+        Contour c{points.size(), 0, sx, sy, sx, sy};
+        int s = 4;
+        const int s_stop = 4;
+        int x2, y2;
+        do {
+            s = (s - 1) & 7;
+            x2 = sx + kDx[s]; y2 = sy + kDy[s];
+        } while (!set(x2, y2) && s != s_stop);
+        if (s == s_stop) {  // isolated pixel
+            mark_right(sx, sy);
+            points.push_back({sx, sy});
+        } else {
+            int cx = sx, cy = sy, nx = 0, ny = 0;
+            int prev_dir = s ^ 4;
+            for (;;) {
+                const int s_from = s;
+                while (s < 15) {
+                    ++s;
+                    nx = cx + kDx[s & 7]; ny = cy + kDy[s & 7];
+                    if (set(nx, ny)) break;
+                }
+                s &= 7;
+                if ((unsigned)(s - 1) < (unsigned)s_from) mark_right(cx, cy);
+                else mark_plain(cx, cy);
+                if (s != prev_dir) {
+                    points.push_back({cx, cy});
+                    c.x0 = std::min(c.x0, cx); c.x1 = std::max(c.x1, cx);
+                    c.y0 = std::min(c.y0, cy); c.y1 = std::max(c.y1, cy);
+                    prev_dir = s;
+                }
+                if (nx == sx && ny == sy && cx == x2 && cy == y2) break;
+                cx = nx; cy = ny;
+                s = (s + 4) & 7;
+            }
+        }
+        c.count = points.size() - c.first;
+        contours.push_back(c);
+    }
+
+    const uint32_t *b_;
+    int h_, w_, wpr_;
+    uint32_t *t_ = nullptr, *r_ = nullptr;
+    Planes *pl_ = nullptr;
 };
 
 double contour_area(const Pt *p, size_t n)
@@ -335,7 +508,8 @@ std::vector<Pt> approx_poly(const Pt *src, int count, double eps, bool closed_in
     return dst;
 }
 
-bool grid_corners_from(BorderScanner &sc, int H, int W, double min_area_ratio, double eps_ratio, int *out8);
+template <class Scanner>
+bool grid_corners_from(Scanner &sc, int H, int W, double min_area_ratio, double eps_ratio, int *out8);
 
 // find_grid_contour, cv/grid.py:37-71
 bool grid_corners(const u8 *bin, int H, int W, ptrdiff_t pitch, double min_area_ratio, double eps_ratio, int *out8)
@@ -344,7 +518,8 @@ bool grid_corners(const u8 *bin, int H, int W, ptrdiff_t pitch, double min_area_
     return grid_corners_from(sc, H, W, min_area_ratio, eps_ratio, out8);
 }
 
-bool grid_corners_from(BorderScanner &sc, int H, int W, double min_area_ratio, double eps_ratio, int *out8)
+template <class Scanner>
+bool grid_corners_from(Scanner &sc, int H, int W, double min_area_ratio, double eps_ratio, int *out8)
 {
     sc.run();
     const double min_area = min_area_ratio * ((double)H * (double)W);
@@ -400,7 +575,7 @@ extern "C" int sv_find_grid_corners_bits_batch(const uint32_t *bits, int n, int 
     if (threads < 1) threads = 1;
     if (threads > n) threads = n;
     WorkerPool::instance().parallel_for(n, threads, [&](int i) {
-        BorderScanner sc(bits + (size_t)i * H * (W >> 5), H, W);
+        BitScanner sc(bits + (size_t)i * H * (W >> 5), H, W);
         found[i] = grid_corners_from(sc, H, W, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
     });
     return SV_OK;
@@ -416,6 +591,28 @@ extern "C" int sv_find_contours_u8(const uint8_t *binary, int H, int W, ptrdiff_
     *n_contours = (int)sc.contours.size();
     if ((long)sc.points.size() > cap_points || (int)sc.contours.size() > cap_contours || !points || !sizes)
         return sv_fail(SV_ERR_BUFFER, "sv_find_contours_u8: need room for %ld points in %d contours", *n_points, *n_contours);
+    long w = 0;
+    int ci = 0;
+    for (size_t k = sc.contours.size(); k-- > 0; ci++) {  // cv2 order: last found first
+        const Contour &c = sc.contours[k];
+        sizes[ci] = (int)c.count;
+        for (size_t i = 0; i < c.count; i++) { points[2 * w] = sc.points[c.first + i].x; points[2 * w + 1] = sc.points[c.first + i].y; w++; }
+    }
+    return SV_OK;
+}
+
+// the same from a bit-packed image (BitScanner): what sv_find_grid_corners_bits_batch runs on, exposed so that tests can compare
+// the two scanners contour by contour
+extern "C" int sv_find_contours_bits(const uint32_t *bits, int H, int W, int *points, long cap_points, int *sizes, int cap_contours,
+                                     long *n_points, int *n_contours)
+{
+    if (!bits || !n_points || !n_contours || H <= 0 || W <= 0 || (W & 31)) return sv_fail(SV_ERR_BAD_ARG, "sv_find_contours_bits: bad argument");
+    BitScanner sc(bits, H, W);
+    sc.run();
+    *n_points = (long)sc.points.size();
+    *n_contours = (int)sc.contours.size();
+    if ((long)sc.points.size() > cap_points || (int)sc.contours.size() > cap_contours || !points || !sizes)
+        return sv_fail(SV_ERR_BUFFER, "sv_find_contours_bits: need room for %ld points in %d contours", *n_points, *n_contours);
     long w = 0;
     int ci = 0;
     for (size_t k = sc.contours.size(); k-- > 0; ci++) {  // cv2 order: last found first

@@ -35,6 +35,25 @@ def find_contours(binary):
     return out
 
 
+def find_contours_bits(bits, H, W):
+    """bits uint32/int32 [H, W//32] (1 bit per pixel, LSB = leftmost) -> the same list find_contours gives for the unpacked image."""
+    b = np.ascontiguousarray(bits).view(np.uint32)
+    lib = _native.lib()
+    npts, ncont = C.c_long(), C.c_int()
+    rc = lib.sv_find_contours_bits(b.ctypes.data_as(C.c_void_p), int(H), int(W), None, 0, None, 0, C.byref(npts), C.byref(ncont))
+    if rc not in (0, -6):
+        _native.check(rc, "sv_find_contours_bits")
+    pts = np.empty((max(npts.value, 1), 2), np.int32)
+    sizes = np.empty(max(ncont.value, 1), np.int32)
+    _native.check(lib.sv_find_contours_bits(b.ctypes.data_as(C.c_void_p), int(H), int(W), pts.ctypes.data_as(C.c_void_p), npts.value,
+                                            sizes.ctypes.data_as(C.c_void_p), ncont.value, C.byref(npts), C.byref(ncont)), "sv_find_contours_bits")
+    out, o = [], 0
+    for i in range(ncont.value):
+        out.append(pts[o:o + sizes[i]].reshape(-1, 1, 2).copy())
+        o += sizes[i]
+    return out
+
+
 def _pts(contour):
     return np.ascontiguousarray(np.asarray(contour).reshape(-1, 2), np.int32)
 

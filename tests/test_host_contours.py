@@ -94,6 +94,29 @@ def test_product_equals_oracle_on_blobs(host, seed):
         assert (g is None) == (go is None) and (g is None or (g == go).all())
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_bit_scanner_equals_byte_scanner(host, seed):
+    """The scanner the batched pipeline uses works on the bit-packed image without expanding it (labels in two side bit planes,
+    the raster scan visits only label pixels and run starts and jumps from a positive label to the next right-exit).  Contour by
+    contour -- points, order -- it gives what the byte-image scanner gives: blobs at several densities (nested components,
+    touching image borders, 1-pixel specks), widths 32..416, a frame-like case with a big outline full of clutter, and the
+    reused per-thread planes (two different images back to back)."""
+    rs = np.random.RandomState(seed)
+    for h, w, thr in ((64, 32, 0.5), (97, 160, 0.45), (200, 416, 0.6), (130, 96, 0.3)):
+        img = _blobs(seed * 7 + h, h, w, thr)
+        img[rs.randint(0, h, 30), rs.randint(0, w, 30)] = 255             # specks, some on the border
+        if seed % 2:
+            img[5:h - 5, 4] = 255; img[5:h - 5, w - 5] = 255; img[5, 4:w - 4] = 255; img[h - 6, 4:w - 4] = 255   # an outline around the clutter
+        bits = np.packbits(img > 0, axis=1, bitorder="little").view(np.uint32)
+        a, b = host.find_contours(img), host.find_contours_bits(bits, h, w)
+        assert len(a) == len(b)
+        for ca, cb in zip(a, b):
+            assert ca.shape == cb.shape and (ca == cb).all()
+        got_c, got_f = host.find_grid_corners_bits_batch(bits[None], h, w, 0.1, 0.02, 1)
+        want = host.find_grid_corners(img)
+        assert bool(got_f[0]) == (want is not None) and (want is None or (got_c[0] == want).all())
+
+
 def test_synthetic_frames_corners(host):
     from sudoku_vision_amd.synth import synth_frames
     frames, corners, _ = synth_frames(3, 540, 960, seed=12)

@@ -103,6 +103,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
     if (ncell == 0) return;
 
     if (!consumer) {
+        // the producers are the younger half of the workgroup and would lose every issue arbitration against the consumers' MFMA
+        // stream on their SIMD; their instructions are few and the consumers wait for them at the barrier: static priority
+        __builtin_amdgcn_s_setprio(1);                                          // (0.42 -> 0.375 ms)
         const int ptid = tid & 255;
         // Input of a cell -> inh[slot]: one dword (4 pixels of a row) per thread for 8-bit cells, up to 4 floats for f32 input;
         // every value is split into its f16 pair on the way (pixel (y, x) sits at row y + 1, column x + 1 of a 64-byte row)
@@ -221,88 +224,124 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
     settle(bias2_1);
     __syncthreads();                                                            // (A)
     __syncthreads();                                                            // (B_0)
-    // A consumer is alone on its SIMD's matrix pipe, so every cycle it spends outside MFMAs is idle pipe time (measured: 55 % idle
-    // with a plain tile loop).  Two measures, both relying on the tile loop being fully unrolled (all indices static):
-    //   * A operands flow through an RING-slot register ring filled PF steps (taps) ahead of their MFMAs, across tile boundaries;
-    //     in straight-line code the compiler counts its lgkmcnt waits exactly;
-    //   * accumulators are double-buffered by tile parity and the epilogue of tile j-1 (sum of the two accumulator sets, 2x2 max,
-    //     scale, bias, ReLU, store) is issued in four pieces between the MFMAs of taps 1-4 of tile j.
-    constexpr int PF = 4, RING = 5;
+    // A consumer is alone on its SIMD's matrix pipe, so every cycle it spends outside MFMAs is idle pipe time.  Measured on this
+    // hardware (tools/ubench_mfma_fill.hip, one wave per SIMD, back-to-back v_mfma_f32_16x16x32_f16 = 16.5 cycles each): ONE
+    // VALU instruction or s_waitcnt in the gap behind an MFMA is free, a second one costs 4-5 cycles, a third 8 more; ONE
+    // ds_read_b128 costs 4, a second one 16 more.  So the tile body is written as 54 slots -- an MFMA and at most one other
+    // instruction each, fenced by sched_barrier so the compiler cannot regroup them:
+    //   * the MFMAs are asm so that every accumulation is IN PLACE (vDst = SrcC; left to the register allocator, dependent MFMAs
+    //     got a destination different from their SrcC, which takes the result through the register file instead of the
+    //     accumulate-forwarding path).  Hazards hipcc would pad for a builtin hold by construction: A comes from ds_reads (the
+    //     compiler waits for asm inputs), B was loaded before the loop, a tile's first MFMAs take the literal 0 as SrcC, and the
+    //     VALU reads an accumulator at the earliest 12 MFMAs after its last MFMA;
+    //   * A operands flow through a RING-slot register ring, one ds_read_b128 per slot, PF taps ahead of their MFMAs, across tile
+    //     boundaries (the tile loop is fully unrolled: all ring indices are static and the lgkmcnt waits are counted exactly);
+    //   * all three partial products of a channel tile go into ONE accumulator (f32 either way), double-buffered by tile parity;
+    //     the epilogue of tile j-1 (2x2 max, scale + bias, ReLU, store) is nine single instructions in the slots of taps 2-4.
+    constexpr int PF = 5, RING = 6;
     uint4 ring_h[RING], ring_l[RING];
-    int lane_off = (c16 >> 2) + 64 * ((c16 >> 1) & 1) + 128 * (c16 & 1) + 256 * q;   // window-in-tile | dy | dx | k-group
-    auto tile_base = [&](int buf, int j) -> const unsigned char * {
-        int g = 4 * j + (lane_off & 3);
+    // per-lane LDS offset of this wave's tile jj (window-in-tile, position dy/dx, k-group of the lane): loop-invariant, 7 registers
+    unsigned tile_off[7];
+#pragma unroll
+    for (int jj = 0; jj < 7; jj++) {
+        int g = 4 * (par + 2 * jj) + (c16 >> 2);
         if (g > 48) g = 48;
-        const int wy = g / 7, wx = g - 7 * wy;
-        return c1[buf] + (2 * wy + ((lane_off >> 6) & 1)) * ROW_STRIDE + (2 * wx + ((lane_off >> 7) & 1)) * POS_STRIDE + (lane_off >> 8) * 16;
-    };
+        const int wy = g / 7, wx = g - 7 * wy, sp = c16 & 3;
+        tile_off[jj] = (unsigned)((2 * wy + (sp >> 1)) * ROW_STRIDE + (2 * wx + (sp & 1)) * POS_STRIDE + q * 16);
+    }
 #define SV_TAP_OFF(tap) (((tap) / 3) * ROW_STRIDE + ((tap) % 3) * POS_STRIDE)
+#define SV_SLOT() __builtin_amdgcn_sched_barrier(0)
     const int ntile = (ablate & 2) ? 0 : (par ? 6 : 7);
-    const unsigned out_off = 32 * np + 2 * c16;
+    const unsigned out_off = (32 * np + 2 * c16 + 64 * q + 256 * par) * 4;      // byte offset of (window 4*par + q, channels 32np + 2c16..) in a cell's features
+    unsigned long long dbg_t[4] = {0, 0, 0, 0}, dbg_s = 0;
+#define SV_STAMP(i) do { if (ablate & 16) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); dbg_t[i] += t_ - dbg_s; dbg_s = t_; } } while (0)
+    if (ablate & 16) dbg_s = __builtin_amdgcn_s_memtime();
     for (long k = 0; k < ncell; k++) {
-        // (the per-tile LDS addresses are recomputed every cell -- a dozen VALU instructions per tile beside 54 MFMAs -- instead of
-        // living in 14 registers across the loop: with the 144 B-operand registers this kernel has none to spare)
-        asm volatile("" : "+v"(lane_off));
-        float *fcell = feat + (first + k * stride) * FEAT;                      // wave-uniform: scalar base + 32-bit lane offsets
-        const unsigned char *ap = tile_base((int)(k & 1), par);
+        SV_STAMP(0);
+        const char *fcell = (const char *)(feat + (first + k * stride) * FEAT);  // wave-uniform: scalar base + 32-bit lane offsets
+        const unsigned char *cbase = c1[k & 1];
+        const unsigned char *ap = cbase + tile_off[0], *ap_next = ap;
 #pragma unroll
         for (int st = 0; st < PF; st++) {                                       // the first tile of a cell cannot be fetched before the barrier
             ring_h[st % RING] = *(const uint4 *)(ap + SV_TAP_OFF(st));
             ring_l[st % RING] = *(const uint4 *)(ap + SV_TAP_OFF(st) + PLANE_B);
         }
-        f32x4 acc_h[2][2], acc_l[2][2];                                         // [tile parity][t]
-        float y[2];
-        auto epilogue = [&](int piece, int pj, int set) {                       // tile pj, whose sums sit in accumulator set `set`
-            const int gw = 4 * pj + q;                                          // rows 4q..4q+3 = the 4 positions of window gw
-            if (piece < 2) {
-                const f32x4 v = acc_h[set][piece] + acc_l[set][piece];
-                y[piece] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) * scale_inv;
-            } else if (piece == 2) {
-                y[0] = fmaxf(y[0] + bias2_0, 0.f);
-                y[1] = fmaxf(y[1] + bias2_1, 0.f);
-            } else if (gw < 49) {
-                const unsigned boff = (out_off + (unsigned)gw * 64u) * 4u;         // 32-bit lane offset on a scalar base
-                *(f32x2 *)((char *)fcell + boff) = (f32x2){y[0], y[1]};
+        f32x4 acc[2][2];                                                        // [tile parity][t]
+        float m0 = 0.f, m1 = 0.f;
+        // one single-instruction piece of the epilogue of the tile whose sums sit in accumulator set `set` (tile index jp of this wave)
+        auto epilogue = [&](int piece, int jp, int set) {
+            const f32x4 &v0 = acc[set][0], &v1 = acc[set][1];
+            switch (piece) {                                                    // (asm: fmaxf on asm-produced values gets a canonicalising v_max first)
+            case 0: asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(v0[0]), "v"(v0[1]), "v"(v0[2])); break;
+            case 1: asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(v1[0]), "v"(v1[1]), "v"(v1[2])); break;
+            case 2: asm volatile("v_max_f32 %0, %0, %1" : "+v"(m0) : "v"(v0[3])); break;
+            case 3: asm volatile("v_max_f32 %0, %0, %1" : "+v"(m1) : "v"(v1[3])); break;
+            case 4: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(m0) : "s"(scale_inv), "v"(bias2_0)); break;
+            case 5: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(m1) : "s"(scale_inv), "v"(bias2_1)); break;
+            case 6: asm volatile("v_max_f32 %0, 0, %0" : "+v"(m0)); break;
+            case 7: asm volatile("v_max_f32 %0, 0, %0" : "+v"(m1)); break;
+            default:                                                            // rows 4q..4q+3 = the 4 positions of window 4*(par + 2jp) + q
+                if (jp < 6 || q == 0) *(f32x2 *)(fcell + jp * 2048 + out_off) = (f32x2){m0, m1};
             }
         };
         // 13 M tiles of 4 pooling windows; this wave takes tiles par, par+2, ... for its 32 channels
 #pragma unroll
         for (int jj = 0; jj < 7; jj++) {
             if (jj >= ntile) break;
-            const int j = par + 2 * jj, set = jj & 1;
-            const unsigned char *ap_next = tile_base((int)(k & 1), j + 2 < 13 ? j + 2 : j);
-#pragma unroll
-            for (int t = 0; t < 2; t++) { acc_h[set][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc_l[set][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            const int set = jj & 1;
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
                 const int st = jj * 9 + tap;                                    // step number within the cell
-                if (tap + PF < 9) {
-                    ring_h[(st + PF) % RING] = *(const uint4 *)(ap + SV_TAP_OFF(tap + PF));
-                    ring_l[(st + PF) % RING] = *(const uint4 *)(ap + SV_TAP_OFF(tap + PF) + PLANE_B);
-                } else if (jj + 1 < ntile) {
-                    ring_h[(st + PF) % RING] = *(const uint4 *)(ap_next + SV_TAP_OFF(tap + PF - 9));
-                    ring_l[(st + PF) % RING] = *(const uint4 *)(ap_next + SV_TAP_OFF(tap + PF - 9) + PLANE_B);
-                }
-                __builtin_amdgcn_sched_barrier(0);                              // keep the fetch ahead of this tap's MFMAs
+                const bool pf_here = tap + PF < 9, pf_next = !pf_here && jj + 1 < ntile;
+                const unsigned char *pa = pf_here ? ap + SV_TAP_OFF((tap + PF) % 9) : ap_next + SV_TAP_OFF((tap + PF) % 9);
                 const h8 ah = __builtin_bit_cast(h8, ring_h[st % RING]), al = __builtin_bit_cast(h8, ring_l[st % RING]);
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const h8 bh = __builtin_bit_cast(h8, breg[tap][t][0]), bl = __builtin_bit_cast(h8, breg[tap][t][1]);
-                    acc_h[set][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc_h[set][t], 0, 0, 0);
-                    acc_l[set][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_l[set][t], 0, 0, 0);
-                    acc_l[set][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_l[set][t], 0, 0, 0);
-                }
-                if (jj > 0 && tap >= 1 && tap <= 4) epilogue(tap - 1, j - 2, set ^ 1);
+                const h8 bh0 = __builtin_bit_cast(h8, breg[tap][0][0]), bl0 = __builtin_bit_cast(h8, breg[tap][0][1]);
+                const h8 bh1 = __builtin_bit_cast(h8, breg[tap][1][0]), bl1 = __builtin_bit_cast(h8, breg[tap][1][1]);
+                const int e0 = (jj > 0 && tap >= 2 && tap <= 4) ? 3 * (tap - 2) : -1;   // epilogue pieces e0, e0+1, e0+2 in this tap
+                // slot 1
+                SV_SLOT();
+                if (tap == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[set][0]) : "v"(ah), "v"(bh0));
+                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[set][0]) : "v"(ah), "v"(bh0));
+                if (pf_here || pf_next) ring_h[(st + PF) % RING] = *(const uint4 *)pa;
+                SV_SLOT();
+                // slot 2
+                if (tap == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[set][1]) : "v"(ah), "v"(bh1));
+                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[set][1]) : "v"(ah), "v"(bh1));
+                if (tap == 1 && jj + 1 < ntile) ap_next = cbase + tile_off[jj + 1 < 7 ? jj + 1 : 6];   // v_add: next tile's address
+                SV_SLOT();
+                // slot 3
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[set][0]) : "v"(ah), "v"(bl0));
+                if (pf_here || pf_next) ring_l[(st + PF) % RING] = *(const uint4 *)(pa + PLANE_B);
+                SV_SLOT();
+                // slot 4
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[set][1]) : "v"(ah), "v"(bl1));
+                if (e0 >= 0) epilogue(e0, jj - 1, set ^ 1);
+                SV_SLOT();
+                // slot 5
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[set][0]) : "v"(al), "v"(bh0));
+                if (e0 >= 0) epilogue(e0 + 1, jj - 1, set ^ 1);
+                SV_SLOT();
+                // slot 6
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[set][1]) : "v"(al), "v"(bh1));
+                if (e0 >= 0) epilogue(e0 + 2, jj - 1, set ^ 1);
+                SV_SLOT();
             }
             ap = ap_next;
         }
+        SV_STAMP(1);
         if (ntile > 0) {
-            const int jl = par + 2 * (ntile - 1), setl = (ntile - 1) & 1;
+            asm volatile("s_nop 15\n\ts_nop 15");                              // the last tile's accumulators: MFMA -> VALU read distance
 #pragma unroll
-            for (int piece = 0; piece < 4; piece++) epilogue(piece, jl, setl);
+            for (int piece = 0; piece < 9; piece++) epilogue(piece, ntile - 1, (ntile - 1) & 1);
         }
+        SV_STAMP(2);
         __syncthreads();                                                        // (B_{k+1}) / (C)
+        SV_STAMP(3);
     }
+    if ((ablate & 16) && blockIdx.x < 2 && lane == 0)
+        printf("blk %d wave %d ncell %ld: loop-top %llu tiles %llu epilogue %llu barrier %llu cycles/cell\n", (int)blockIdx.x, wave, ncell, dbg_t[0] / ncell, dbg_t[1] / ncell,
+               dbg_t[2] / ncell, dbg_t[3] / ncell);
+#undef SV_SLOT
 #undef SV_TAP_OFF
 }
 
@@ -425,7 +464,8 @@ int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *
 {
     const sv_weights &w = ctx->w;
     const int grid = (int)(B < (long)ctx->num_cus ? B : (long)ctx->num_cus);
-    // tuning aid (wrong results): SV_H2_ABLATE bit 0 skips the producers' conv1 tiles, bit 1 the consumers' conv2 tiles
+    // tuning aid: SV_H2_ABLATE bit 0 skips the producers' conv1 tiles, bit 1 the consumers' conv2 tiles (wrong results); bit 4 makes
+    // the consumer waves of workgroups 0 and 1 print s_memtime stamps of their per-cell phases
     static const int ablate = getenv("SV_H2_ABLATE") ? atoi(getenv("SV_H2_ABLATE")) : 0;
     {
         sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);

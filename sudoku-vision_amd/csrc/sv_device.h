@@ -31,14 +31,20 @@ __host__ __device__ __forceinline__ int sv_warp_block_w(int dw, int dh)
     return bw0;
 }
 
-// Destination pixel (dx,dy) -> source cell (sx,sy) and 1/32 fractions (a,b), cv/grid.py:131.
-__device__ __forceinline__ void sv_warp_coord(const double *M, int dx, int dy, int bw, int &sx, int &sy, int &a, int &b)
+// cv2.warpPerspective evaluates the homography at the origin (x0, dy) of each 64-column block of a destination row in double and
+// steps from there: these three values depend on the block and the row only.
+__device__ __forceinline__ void sv_warp_block_origin(const double *M, int x0, int dy, double &X0, double &Y0, double &W0)
 {
-    const int x0 = (dx / bw) * bw, x1 = dx - x0;
-    const double fx0 = (double)x0, fy = (double)dy, fx1 = (double)x1;
-    const double X0 = __dadd_rn(__dadd_rn(__dmul_rn(M[0], fx0), __dmul_rn(M[1], fy)), M[2]);
-    const double Y0 = __dadd_rn(__dadd_rn(__dmul_rn(M[3], fx0), __dmul_rn(M[4], fy)), M[5]);
-    const double W0 = __dadd_rn(__dadd_rn(__dmul_rn(M[6], fx0), __dmul_rn(M[7], fy)), M[8]);
+    const double fx0 = (double)x0, fy = (double)dy;
+    X0 = __dadd_rn(__dadd_rn(__dmul_rn(M[0], fx0), __dmul_rn(M[1], fy)), M[2]);
+    Y0 = __dadd_rn(__dadd_rn(__dmul_rn(M[3], fx0), __dmul_rn(M[4], fy)), M[5]);
+    W0 = __dadd_rn(__dadd_rn(__dmul_rn(M[6], fx0), __dmul_rn(M[7], fy)), M[8]);
+}
+
+// Destination pixel x1 columns right of a block origin -> source cell (sx,sy) and 1/32 fractions (a,b), cv/grid.py:131.
+__device__ __forceinline__ void sv_warp_coord_from(const double *M, double X0, double Y0, double W0, int x1, int &sx, int &sy, int &a, int &b)
+{
+    const double fx1 = (double)x1;
     double Wv = __dadd_rn(W0, __dmul_rn(M[6], fx1));
     Wv = Wv != 0.0 ? __ddiv_rn(32.0, Wv) : 0.0;
     double fX = __dmul_rn(__dadd_rn(X0, __dmul_rn(M[0], fx1)), Wv);
@@ -52,19 +58,37 @@ __device__ __forceinline__ void sv_warp_coord(const double *M, int dx, int dy, i
     b = Y & 31;
 }
 
+// Destination pixel (dx,dy) -> source cell (sx,sy) and 1/32 fractions (a,b)
+__device__ __forceinline__ void sv_warp_coord(const double *M, int dx, int dy, int bw, int &sx, int &sy, int &a, int &b)
+{
+    const int x0 = (dx / bw) * bw;
+    double X0, Y0, W0;
+    sv_warp_block_origin(M, x0, dy, X0, Y0, W0);
+    sv_warp_coord_from(M, X0, Y0, W0, dx - x0, sx, sy, a, b);
+}
+
 __device__ __forceinline__ int sv_tap(const u8 *img, int H, int W, ptrdiff_t pitch, int C, int x, int y, int c)
 {
     if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) return 0;
     return img[(ptrdiff_t)y * pitch + (ptrdiff_t)x * C + c];
 }
 
-// One bilinear sample, 15-bit weights (they sum to 32768), constant-0 border.
+// One bilinear sample at source cell (sx,sy) with fractions (a,b)/32: 15-bit weights (they sum to 32768), constant-0 border.
+template <int C>
+__device__ __forceinline__ void sv_warp_sample(const u8 *img, int H, int W, ptrdiff_t pitch, int sx, int sy, int a, int b, int (&out)[C]);
+
 template <int C>
 __device__ __forceinline__ void sv_warp_px(const u8 *img, int H, int W, ptrdiff_t pitch, const double *M, int dx, int dy,
                                            int bw, int (&out)[C])
 {
     int sx, sy, a, b;
     sv_warp_coord(M, dx, dy, bw, sx, sy, a, b);
+    sv_warp_sample<C>(img, H, W, pitch, sx, sy, a, b, out);
+}
+
+template <int C>
+__device__ __forceinline__ void sv_warp_sample(const u8 *img, int H, int W, ptrdiff_t pitch, int sx, int sy, int a, int b, int (&out)[C])
+{
     const int w00 = (32 - a) * (32 - b) * 32, w01 = a * (32 - b) * 32, w10 = (32 - a) * b * 32, w11 = a * b * 32;
     const bool inside = (unsigned)sx < (unsigned)(W - 1) && (unsigned)sy < (unsigned)(H - 1);
     if (inside) {

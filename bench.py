@@ -196,15 +196,21 @@ def main():
             budget //= world
         host_threads = max(1, min(16, budget) - 2)
         pipe = FramePipeline(ctx, H, W, chunk=64 if n % 64 == 0 else 32, host_threads=host_threads)
-        pipe.run(frames, out=out)                     # warm-up (page-locks, thread start)
-        barrier()
-        t1 = time.perf_counter()
-        res_e2e = pipe.run(frames, out=out, repeat=args.e2e_passes)     # the pool streamed e2e_passes times, pipeline kept full
-        barrier()
-        dt = time.perf_counter() - t1
-        dt = sharding.max_over_ranks(dt)
+        pipe.run(frames, out=out, repeat=2)           # warm-up (page-locks, thread start)
+        # three timed segments of e2e_passes passes each; the figure is their median and all three are reported: on a shared host a
+        # segment now and then contains a 40-60 ms stall of one search call (tools/dev/search_outliers.py: about one call in 3000,
+        # with or without GPU work in flight), which says nothing about the pipeline
+        segs = []
+        for _ in range(3):
+            barrier()
+            t1 = time.perf_counter()
+            res_e2e = pipe.run(frames, out=out, repeat=args.e2e_passes)     # the pool streamed e2e_passes times, pipeline kept full
+            barrier()
+            segs.append(sharding.max_over_ranks(time.perf_counter() - t1))
+        dt = sorted(segs)[1]
         err = np.abs(res_e2e["corners"].astype(np.float32)[:, :, None, :] - corners[:, None, :, :]).sum(-1).min(-1).max()
         e2e = {"value": n * args.e2e_passes * world / dt, "unit": "frames/s", "host_threads_per_gpu": host_threads,
+               "segments": [n * args.e2e_passes * world / t for t in segs], "aggregate": "median of the segments",
                "grids_found": int(res_e2e["found"].sum()), "of": n, "max_corner_error_px": float(err),
                "note": pipe.describe()}
 

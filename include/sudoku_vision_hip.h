@@ -125,6 +125,24 @@ int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int 
 int sv_despeckle_u8(sv_ctx *ctx, const uint8_t *binary /*dev, n*H*W*/, int n, int H, int W,
                     uint8_t *out /*dev, n*H*W*/, uint32_t *packed /*dev, n*H*W/32, or NULL*/, void *stream);
 
+/* Sparse form of sv_despeckle_u8's packed output for the D2H copy (a despeckled frame is mostly zero words: the hand-over to
+ * the host search shrinks 3-4x).  Record of one frame, little endian:
+ *   u32 n_values, u32 cap_values, u64 mask[H * gpr], u32 value[cap_values]        gpr = ceil(W/32/64)
+ * mask[y * gpr + g] bit k = word 64g + k of row y is non-zero; the non-zero words follow in raster order.  n_values >
+ * cap_values: the frame did not fit (values truncated) -- use the dense image for it.  cap_values is what fits in
+ * record_stride (a multiple of 8; sv_sparse_bits_record_bytes gives the stride for a wanted capacity).
+ * sv_find_grid_corners_sparse_batch / sv_sparse_bits_expand read records on the host. */
+long sv_sparse_bits_record_bytes(int H, int W, long cap_values);
+int sv_pack_sparse_bits(sv_ctx *ctx, const uint32_t *bits /*dev, n*H*W/32*/, int n, int H, int W,
+                        uint8_t *records /*dev, n*record_stride*/, long record_stride, void *stream);
+
+/* Device -> pinned host copy done by a kernel (16-byte stores into mapped host memory) instead of the DMA engine: the
+ * hand-over of the binary to the host corner search (the reference hands cv2.findContours a numpy array, cv/grid.py:18;
+ * here the array has to cross PCIe first).  ~55 GB/s against 22-30 for hipMemcpyAsync on the MI355X boxes measured
+ * (tools/ubench_d2h.hip).  dst_host must be pinned host memory (hipHostMalloc, hipHostRegister, torch pin_memory) --
+ * SV_ERR_BAD_ARG otherwise; both pointers 16-byte aligned.  Stream-ordered like a hipMemcpyAsync. */
+int sv_copy_to_pinned_host(sv_ctx *ctx, const void *src /*dev*/, void *dst_host /*pinned host*/, size_t bytes, void *stream);
+
 /* ---- host corner search (cv/grid.py:16-71; stays on the CPU, no context, no GPU) ----------------- */
 
 /* find_grid_contour(binary, min_area_ratio), cv/grid.py:37-71, with approximate_polygon's
@@ -144,6 +162,20 @@ int sv_find_grid_corners_batch_u8(const uint8_t *binary /*host*/, int n, int H, 
 int sv_find_grid_corners_bits_batch(const uint32_t *bits /*host, n*H*W/32*/, int n, int H, int W,
                                     double min_area_ratio, double epsilon_ratio,
                                     int *corners /*host, n*8*/, uint8_t *found /*host, n*/, int threads);
+
+/* Restrict the library's host worker threads (the batch searches above, the JPEG entropy decoder) to the given CPUs --
+ * normally the CPUs of the NUMA node the GPU's pinned buffers live on: on a two-socket MI355X host the search runs 10-20 %
+ * slower and with 40-ms outliers when its threads wander to the other socket.  n = 0: no restriction for workers started
+ * later.  The thread that calls a batch function works too and keeps its own mask. */
+int sv_host_pool_set_affinity(const int *cpus /*host, n*/, int n);
+
+/* The same on sparse records (sv_pack_sparse_bits).  found[i] = 2: record i overflowed, search its dense image instead. */
+int sv_find_grid_corners_sparse_batch(const uint8_t *records /*host, n*record_stride*/, long record_stride, int n, int H, int W,
+                                      double min_area_ratio, double epsilon_ratio,
+                                      int *corners /*host, n*8*/, uint8_t *found /*host, n*/, int threads);
+
+/* One sparse record -> the dense bit image (H*W/32 words).  SV_ERR_BUFFER if the record overflowed. */
+int sv_sparse_bits_expand(const uint8_t *record /*host*/, int H, int W, uint32_t *bits /*host, H*W/32*/);
 
 /* find_contours(), cv/grid.py:16-21.  Contours in cv2's order, concatenated: points = (x,y) pairs,
  * sizes[i] = vertices of contour i.  If a buffer is too small (or NULL) returns SV_ERR_BUFFER with

@@ -29,6 +29,12 @@ SIGNATURES = {
     "sv_preprocess_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
     "sv_solve_sudoku": [_p, _p, _p],
     "sv_despeckle_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
+    "sv_copy_to_pinned_host": [_p, _p, _p, C.c_size_t, _p],
+    "sv_sparse_bits_record_bytes": [_i, _i, _l],
+    "sv_pack_sparse_bits": [_p, _p, _i, _i, _i, _p, _l, _p],
+    "sv_find_grid_corners_sparse_batch": [_p, _l, _i, _i, _i, _d, _d, _p, _p, _i],
+    "sv_sparse_bits_expand": [_p, _i, _i, _p],
+    "sv_host_pool_set_affinity": [_p, _i],
     "sv_find_grid_corners_bits_batch": [_p, _i, _i, _i, _d, _d, _p, _p, _i],
     "sv_corners_to_minv": [_p, _i, _i, _f, _p],
     "sv_corners_to_minv_batch": [_p, _i, _i, _f, _p, _p],
@@ -56,7 +62,7 @@ SIGNATURES = {
     "sv_cnn_forward_cells_u8": [_p, _p, _l, _i, _p, _p, _p, _p],
     "sv_frames_to_digits": [_p, _p, _i, _i, _i, _pd, _pd, _p, _i, _p, _p, _p, _p, _p],
 }
-_RESTYPES = {"sv_last_error": C.c_char_p}
+_RESTYPES = {"sv_last_error": C.c_char_p, "sv_sparse_bits_record_bytes": C.c_long}
 
 
 

@@ -581,6 +581,56 @@ extern "C" int sv_find_grid_corners_bits_batch(const uint32_t *bits, int n, int 
     return SV_OK;
 }
 
+// sparse record (include/sudoku_vision_hip.h, sv_pack_sparse_bits) -> dense bit image; false if the record overflowed
+static bool sparse_expand(const uint8_t *record, int H, int W, uint32_t *bits)
+{
+    const int wpr = W >> 5, gpr = (wpr + 63) / 64;
+    uint32_t head[2];
+    memcpy(head, record, 8);
+    if (head[0] > head[1]) return false;
+    const uint64_t *masks = reinterpret_cast<const uint64_t *>(record + 8);
+    const uint32_t *val = reinterpret_cast<const uint32_t *>(record + 8 + 8 * (size_t)H * gpr);
+    memset(bits, 0, (size_t)H * wpr * 4);
+    for (int y = 0; y < H; y++)
+        for (int g = 0; g < gpr; g++) {
+            uint64_t m = masks[(size_t)y * gpr + g];
+            uint32_t *row = bits + (size_t)y * wpr + 64 * g;
+            while (m) { row[__builtin_ctzll(m)] = *val++; m &= m - 1; }
+        }
+    return true;
+}
+
+extern "C" int sv_sparse_bits_expand(const uint8_t *record, int H, int W, uint32_t *bits)
+{
+    if (!record || !bits || H <= 0 || W <= 0 || (W & 31) || ((uintptr_t)record & 7)) return sv_fail(SV_ERR_BAD_ARG, "sv_sparse_bits_expand: bad argument");
+    if (!sparse_expand(record, H, W, bits)) return sv_fail(SV_ERR_BUFFER, "sv_sparse_bits_expand: the record overflowed its capacity");
+    return SV_OK;
+}
+
+extern "C" int sv_find_grid_corners_sparse_batch(const uint8_t *records, long record_stride, int n, int H, int W, double min_area_ratio, double epsilon_ratio,
+                                                 int *corners, uint8_t *found, int threads)
+{
+    if (!records || !corners || !found || n <= 0 || H <= 0 || W <= 0 || (W & 31) || (record_stride & 7) || ((uintptr_t)records & 7))
+        return sv_fail(SV_ERR_BAD_ARG, "sv_find_grid_corners_sparse_batch: bad argument");
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    WorkerPool::instance().parallel_for(n, threads, [&](int i) {
+        static thread_local std::vector<uint32_t> dense;
+        dense.resize((size_t)H * (W >> 5));
+        if (!sparse_expand(records + (size_t)i * record_stride, H, W, dense.data())) { found[i] = 2; return; }
+        BitScanner sc(dense.data(), H, W);
+        found[i] = grid_corners_from(sc, H, W, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
+    });
+    return SV_OK;
+}
+
+extern "C" int sv_host_pool_set_affinity(const int *cpus, int n)
+{
+    if (n < 0 || (n > 0 && !cpus)) return sv_fail(SV_ERR_BAD_ARG, "sv_host_pool_set_affinity: bad argument");
+    WorkerPool::instance().set_affinity(cpus, n);
+    return SV_OK;
+}
+
 extern "C" int sv_find_contours_u8(const uint8_t *binary, int H, int W, ptrdiff_t pitch, int *points, long cap_points, int *sizes,
                                    int cap_contours, long *n_points, int *n_contours)
 {

@@ -5,6 +5,8 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -31,8 +33,21 @@ class WorkerPool {
         fn_ = nullptr;
     }
 
+    // Restrict the workers (present and future) to these CPUs; n == 0 lifts the restriction for future workers only.  The caller of
+    // parallel_for works too and keeps its own mask.
+    void set_affinity(const int *cpus, int n)
+    {
+        std::lock_guard<std::mutex> call_lock(call_mu_);
+        CPU_ZERO(&cpus_);
+        have_cpus_ = n > 0;
+        for (int i = 0; i < n; i++)
+            if (cpus[i] >= 0 && cpus[i] < CPU_SETSIZE) CPU_SET(cpus[i], &cpus_);
+        if (have_cpus_)
+            for (auto &t : workers_) pthread_setaffinity_np(t.native_handle(), sizeof(cpus_), &cpus_);
+    }
+
   private:
-    WorkerPool() = default;
+    WorkerPool() { CPU_ZERO(&cpus_); }
     ~WorkerPool()
     {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
@@ -44,6 +59,7 @@ class WorkerPool {
         while ((int)workers_.size() < k) {
             const int id = (int)workers_.size();
             workers_.emplace_back([this, id] { loop(id); });
+            if (have_cpus_) pthread_setaffinity_np(workers_.back().native_handle(), sizeof(cpus_), &cpus_);
         }
     }
     void drain()
@@ -77,4 +93,6 @@ class WorkerPool {
     int n_ = 0, active_ = 0, pending_ = 0;
     unsigned long gen_ = 0;
     bool stop_ = false;
+    cpu_set_t cpus_;
+    bool have_cpus_ = false;
 };

@@ -109,7 +109,87 @@ __global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u
     }
 }
 
+// Device -> mapped pinned host memory with plain 16-byte stores.  On this platform the shader's PCIe writes run at ~55 GB/s where
+// hipMemcpyAsync's DMA engine delivers 22-30 (tools/ubench_d2h.hip), and 64 small workgroups are enough to saturate the link.
+__global__ __launch_bounds__(256) void k_copy_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16, const u8 *__restrict__ tail_src,
+                                                      u8 *__restrict__ tail_dst, int tail)
+{
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) tail_dst[threadIdx.x] = tail_src[threadIdx.x];
+}
+
+// The despeckled bit image of a frame is mostly zero words (1080p synthetic feed: 13 k of 64.8 k words are not), and the D2H copy of it is
+// what bounds the end-to-end rate once the host search is fast.  Sparse record of a frame (sv_pack_sparse_bits):
+//   u32 n_values, u32 cap_values, u64 mask[H * gpr], u32 value[cap_values]
+// one mask per row and group of 64 words (gpr = ceil(W/32/64) groups per row), bit k = word 64*group + k of the row is non-zero; the
+// non-zero words follow in raster order.  n_values > cap_values = the record overflowed (values truncated; the caller falls back to the
+// dense image).  One workgroup per frame: masks + counts, a scan of the counts in LDS, then the scatter.
+__global__ __launch_bounds__(1024) void k_pack_sparse(const u32 *__restrict__ bits, int H, int wpr, int gpr, u8 *__restrict__ records, long stride,
+                                                      unsigned cap_values)
+{
+    extern __shared__ u32 cnt[];                     // [G] counts, then exclusive offsets; [16] wave sums behind them
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = H * gpr;
+    u32 *wsum = cnt + G;
+    const u32 *fb = bits + (size_t)blockIdx.x * H * wpr;
+    u8 *rec = records + (size_t)blockIdx.x * stride;
+    u64 *masks = (u64 *)(rec + 8);
+    u32 *values = (u32 *)(rec + 8 + 8 * (size_t)G);
+    for (int g = wave; g < G; g += 16) {
+        const int y = g / gpr, k = (g - y * gpr) * 64 + lane;
+        const u32 w = k < wpr ? fb[(size_t)y * wpr + k] : 0u;
+        const u64 m = __ballot(w != 0);
+        if (lane == 0) { masks[g] = m; cnt[g] = (u32)__popcll(m); }
+    }
+    __syncthreads();
+    const int per = (G + 1023) / 1024, lo = tid * per, hi = lo + per < G ? lo + per : G;
+    u32 mine = 0;
+    for (int i = lo; i < hi; i++) mine += cnt[i];
+    u32 incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 base = 0, total = 0;
+    for (int w2 = 0; w2 < 16; w2++) { const u32 v = wsum[w2]; if (w2 < wave) base += v; total += v; }
+    u32 run = base + incl - mine;
+    for (int i = lo; i < hi; i++) { const u32 c = cnt[i]; cnt[i] = run; run += c; }
+    __syncthreads();
+    for (int g = wave; g < G; g += 16) {
+        const int y = g / gpr, k = (g - y * gpr) * 64 + lane;
+        const u32 w = k < wpr ? fb[(size_t)y * wpr + k] : 0u;
+        const u64 m = __ballot(w != 0);
+        const u32 pos = cnt[g] + (u32)__popcll(m & ((1ull << lane) - 1));
+        if (w && pos < cap_values) values[pos] = w;
+    }
+    if (tid == 0) { ((u32 *)rec)[0] = total; ((u32 *)rec)[1] = cap_values; }
+}
+
 }  // namespace
+
+int svk_pack_sparse_bits(const u32 *bits, int n, int H, int W, u8 *records, long stride, hipStream_t s)
+{
+    const int wpr = W >> 5, gpr = (wpr + 63) / 64, G = H * gpr;
+    const long cap = (stride - 8 - 8L * G) / 4;
+    hipLaunchKernelGGL(k_pack_sparse, dim3((unsigned)n), dim3(1024), (size_t)(G + 16) * 4, s, bits, H, wpr, gpr, records, stride,
+                       (unsigned)(cap > 0xffffffffL ? 0xffffffffL : cap));
+    SV_LAUNCH_CHECK("k_pack_sparse");
+    return SV_OK;
+}
+
+int svk_copy_to_host(const void *src, void *dst_host, size_t bytes, hipStream_t s)
+{
+    const size_t n16 = bytes / 16;
+    const int tail = (int)(bytes - n16 * 16);
+    size_t wgs = (n16 + 255) / 256;
+    wgs = wgs < 1 ? 1 : (wgs > 64 ? 64 : wgs);
+    hipLaunchKernelGGL(k_copy_to_host, dim3((unsigned)wgs), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst_host, n16, (const u8 *)src + n16 * 16,
+                       (u8 *)dst_host + n16 * 16, tail);
+    SV_LAUNCH_CHECK("k_copy_to_host");
+    return SV_OK;
+}
 
 // two passes (tile grids offset by half a tile); dst may equal src.  With `packed` (needs W % 32 == 0) the second pass
 // writes 1 bit per pixel there instead of bytes into dst (dst then holds the first pass only and serves as scratch).

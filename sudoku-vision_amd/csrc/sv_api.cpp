@@ -505,6 +505,36 @@ extern "C" int sv_despeckle_u8(sv_ctx *ctx, const uint8_t *binary, int n, int H,
     return svk_despeckle(binary, n, H, W, out, packed, S(stream));
 }
 
+extern "C" long sv_sparse_bits_record_bytes(int H, int W, long cap_values)
+{
+    if (H <= 0 || W <= 0 || (W & 31) || cap_values < 0) return -1;
+    const long gpr = ((W >> 5) + 63) / 64;
+    return (8 + 8 * gpr * H + 4 * cap_values + 15) / 16 * 16;
+}
+
+extern "C" int sv_pack_sparse_bits(sv_ctx *ctx, const uint32_t *bits, int n, int H, int W, uint8_t *records, long record_stride, void *stream)
+{
+    REQUIRE(ctx && bits && records, "NULL argument");
+    REQUIRE(n > 0 && H > 0 && W > 0 && W % 32 == 0, "bad shape (W must be a multiple of 32)");
+    const long G = (long)H * (((W >> 5) + 63) / 64);
+    REQUIRE(G <= 16000, "frame too large for the sparse record (more than 16000 row groups)");
+    REQUIRE(record_stride % 8 == 0 && record_stride >= 8 + 8 * G + 4 && ((uintptr_t)records & 7) == 0, "record stride must be a multiple of 8 with room for the masks");
+    return svk_pack_sparse_bits(bits, n, H, W, records, record_stride, S(stream));
+}
+
+extern "C" int sv_copy_to_pinned_host(sv_ctx *ctx, const void *src, void *dst_host, size_t bytes, void *stream)
+{
+    REQUIRE(ctx && src && dst_host, "NULL argument");
+    REQUIRE((((uintptr_t)src | (uintptr_t)dst_host) & 15) == 0, "source and destination must be 16-byte aligned");
+    if (bytes == 0) return SV_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dst_host) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return sv_fail(SV_ERR_BAD_ARG, "sv_copy_to_pinned_host: destination is not pinned (hipHostMalloc / hipHostRegister) host memory");
+    }
+    return svk_copy_to_host(src, dst_host, bytes, S(stream));
+}
+
 extern "C" int sv_warp_perspective_u8(sv_ctx *ctx, const uint8_t *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size, uint8_t *dst, void *stream)
 {
     REQUIRE(ctx && img && minv && dst, "NULL argument");

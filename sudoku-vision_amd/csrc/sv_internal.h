@@ -92,6 +92,8 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
                     hipStream_t s);
 
 int svk_despeckle(const u8 *src, int n, int H, int W, u8 *dst, unsigned *packed, hipStream_t s);
+int svk_pack_sparse_bits(const uint32_t *bits, int n, int H, int W, u8 *records, long stride, hipStream_t s);
+int svk_copy_to_host(const void *src, void *dst_host, size_t bytes, hipStream_t s);
 int svk_resize_linear(const u8 *src, int sh, int sw, ptrdiff_t pitch, u8 *dst, int dh, int dw, hipStream_t s);
 int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8 *digits, float *conf, hipStream_t s);
 int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, hipStream_t s);

@@ -122,6 +122,43 @@ def find_grid_corners_bits_batch(bits, H, W, min_area_ratio=0.1, epsilon_ratio=0
     return corners, found.astype(bool)
 
 
+def set_pool_affinity(cpus):
+    """Restrict the library's host worker threads to these CPUs (an iterable of ints; empty = no restriction for new workers)."""
+    a = np.ascontiguousarray(sorted(int(c) for c in cpus), np.int32)
+    _native.check(_native.lib().sv_host_pool_set_affinity(a.ctypes.data_as(C.c_void_p) if a.size else None, int(a.size)), "sv_host_pool_set_affinity")
+
+
+def sparse_bits_record_bytes(H, W, cap_values):
+    """Bytes of one sparse record (sv_pack_sparse_bits) with room for cap_values non-zero words."""
+    r = _native.lib().sv_sparse_bits_record_bytes(int(H), int(W), int(cap_values))
+    if r < 0:
+        raise ValueError("bad shape for a sparse record (W must be a multiple of 32)")
+    return int(r)
+
+
+def find_grid_corners_sparse_batch(records, H, W, min_area_ratio=0.1, epsilon_ratio=0.02, threads=None):
+    """records uint8 [n,stride] (host; Context.pack_sparse_bits' output after the D2H copy) -> (corners int32 [n,4,2], found uint8 [n]);
+    found[i] == 2: record i overflowed its capacity and has to be searched from the dense bit image."""
+    if records.dtype != np.uint8 or records.ndim != 2 or not records.flags.c_contiguous:
+        raise TypeError("records must be a C-contiguous uint8 [n,stride] array")
+    n, stride = records.shape
+    corners = np.zeros((n, 4, 2), np.int32)
+    found = np.zeros(n, np.uint8)
+    threads = threads or min(n, os.cpu_count() or 1)
+    _native.check(_native.lib().sv_find_grid_corners_sparse_batch(records.ctypes.data_as(C.c_void_p), stride, n, int(H), int(W), float(min_area_ratio),
+                                                                  float(epsilon_ratio), corners.ctypes.data_as(C.c_void_p),
+                                                                  found.ctypes.data_as(C.c_void_p), int(threads)), "sv_find_grid_corners_sparse_batch")
+    return corners, found
+
+
+def sparse_bits_expand(record, H, W):
+    """One sparse record (uint8 [stride], host) -> the dense bit image uint32 [H, W//32]."""
+    rec = np.ascontiguousarray(record, np.uint8)
+    out = np.empty((H, W // 32), np.uint32)
+    _native.check(_native.lib().sv_sparse_bits_expand(rec.ctypes.data_as(C.c_void_p), int(H), int(W), out.ctypes.data_as(C.c_void_p)), "sv_sparse_bits_expand")
+    return out
+
+
 def solve_sudoku(grid):
     """grid: 9x9 (or 81) digits, 0 = empty -> (code, solution 9x9 uint8); code 1 solved, 0 no solution, -1 invalid input
     (the reference solver's SOLVE_* codes).  solution == grid unless solved."""

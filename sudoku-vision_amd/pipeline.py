@@ -39,9 +39,36 @@ def host_cpu_budget():
     return n
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(device):
+    """CPUs of the NUMA node the GPU hangs off (sysfs local_cpulist of its PCI function) that this process may run on, or None when
+    the platform does not say.  The pipeline's pinned buffers are first touched, hence placed, there; host threads that wander to the
+    other socket of a two-socket box run the search 10-20 % slower and with 40-ms outliers (tools/dev/e2e_stall_trace.py)."""
+    try:
+        p = torch.cuda.get_device_properties(device)
+        path = f"/sys/bus/pci/devices/{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0/local_cpulist"
+        cpus = _parse_cpulist(open(path).read())
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+    if hasattr(os, "sched_getaffinity"):
+        cpus &= os.sched_getaffinity(0)
+    return cpus or None
+
+
 class FramePipeline:
-    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1, glue=0, despeckle=True):
+    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1, glue=0, despeckle=True, sparse=False, depth=5, cpu_affinity="auto"):
         self.ctx, self.H, self.W, self.chunk = ctx, H, W, chunk
+        # chunks in flight.  A chunk's chain is K1 -> D2H -> search -> K2/K3, and chunk i's K1 is only issued once chunk i-depth+1's search has
+        # returned: with too few in flight the period is (K1 + D2H + search) / (depth - 1), not the slowest stage
+        self.depth = depth = max(2, int(depth))
         self.host_threads = host_threads or max(1, host_cpu_budget() - 2)   # two CPUs left for this thread and the runtime's own
         self.min_area_ratio = min_area_ratio
         # the speck filter is exact only while nothing it can erase (bounding box <= 62x62 px, area <= 61*61) reaches the
@@ -49,24 +76,53 @@ class FramePipeline:
         self.despeckle = bool(despeckle) and min_area_ratio * H * W > 61 * 61
         self.glue = glue            # Context.GLUE_NORMALIZE, or GLUE_RUNPY for run.py's preprocess_cell (CLAHE + threshold)
         dev = ctx.device
-        self.s_pre = torch.cuda.Stream(dev)       # K1 + D2H
+        self.s_pre = torch.cuda.Stream(dev)       # K1 (+ despeckle)
+        self.s_d2h = torch.cuda.Stream(dev)       # the D2H copy on its own stream: in s_pre it would hold back the next chunk's K1 for 0.3 ms
         self.s_cls = torch.cuda.Stream(dev)       # H2D + K2 + K3
         # D2H payload: with despeckle on and W % 32 == 0 the binary crosses PCIe as 1 bit per pixel (W/32 words per row)
         self.packed = self.despeckle and W % 32 == 0
+        # sparse=True: ... as sparse records (row masks + the non-zero words) with room for half of the words; a frame that does not fit is
+        # fetched dense (sv_pack_sparse_bits).  Off by default: it cuts the PCIe bytes 2-3x on the synthetic feed but costs a kernel, and on a
+        # one-GPU box the dense copy (0.30 ms per 64 frames at 55 GB/s) is not what bounds the pipeline (tools/e2e_breakdown.py); it is there for
+        # hosts where eight GPUs share the PCIe root and the host memory bandwidth
+        self.sparse = self.packed and bool(sparse) and H * ((W // 32 + 63) // 64) <= 16000
         if self.packed:
-            self.pinned = [torch.empty((chunk, H, W // 32), dtype=torch.int32).pin_memory() for _ in range(3)]
-            self.dev_bits = [torch.empty((chunk, H, W // 32), dtype=torch.int32, device=dev) for _ in range(3)]
+            self.dev_bits = [torch.empty((chunk, H, W // 32), dtype=torch.int32, device=dev) for _ in range(depth)]
+        if self.sparse:
+            cap = H * (W // 32) // 2 if sparse is True else int(sparse)          # an int: capacity in words (tests force the fallback with it)
+            self.rec_bytes = host.sparse_bits_record_bytes(H, W, cap)
+            self.pinned = [torch.empty((chunk, self.rec_bytes), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+            self.dev_rec = [torch.empty((chunk, self.rec_bytes), dtype=torch.uint8, device=dev) for _ in range(depth)]
+            self.s_side = torch.cuda.Stream(dev)
+        elif self.packed:
+            self.pinned = [torch.empty((chunk, H, W // 32), dtype=torch.int32).pin_memory() for _ in range(depth)]
         else:
-            self.pinned = [torch.empty((chunk, H, W), dtype=torch.uint8).pin_memory() for _ in range(3)]
-        self.dev_bin = [torch.empty((chunk, H, W), dtype=torch.uint8, device=dev) for _ in range(3)]
-        self.minv_pin = [torch.empty((chunk, 9), dtype=torch.float64).pin_memory() for _ in range(3)]
-        self.minv_dev = [torch.empty((chunk, 9), dtype=torch.float64, device=dev) for _ in range(3)]
-        self.pool = ThreadPoolExecutor(1)
+            self.pinned = [torch.empty((chunk, H, W), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self.dev_bin = [torch.empty((chunk, H, W), dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.minv_pin = [torch.empty((chunk, 9), dtype=torch.float64).pin_memory() for _ in range(depth)]
+        self.minv_dev = [torch.empty((chunk, 9), dtype=torch.float64, device=dev) for _ in range(depth)]
+        # host threads next to the GPU: "auto" = the GPU's NUMA node, None = leave them alone, or an explicit set of CPUs.  Applies to the
+        # search thread and the library's workers, not to the caller's thread
+        self.cpus = gpu_local_cpus(dev) if cpu_affinity == "auto" else (set(cpu_affinity) if cpu_affinity else None)
+        if self.cpus:
+            host.set_pool_affinity(self.cpus)
+        self.pool = ThreadPoolExecutor(1, initializer=(lambda: os.sched_setaffinity(0, self.cpus)) if self.cpus and hasattr(os, "sched_setaffinity") else None)
+        self.dense_fallbacks = 0
         ctx.reserve(chunk * 81)
 
     def _search(self, slot, m, ev):
         ev.synchronize()
-        if self.packed:
+        if self.sparse:
+            corners, found = host.find_grid_corners_sparse_batch(self.pinned[slot][:m].numpy(), self.H, self.W, self.min_area_ratio, 0.02, self.host_threads)
+            over = np.nonzero(found == 2)[0]
+            if over.size:                       # records that overflowed: fetch those frames dense (the slot's bit image is still there)
+                with torch.cuda.stream(self.s_side):
+                    dense = self.dev_bits[slot][torch.from_numpy(over).to(self.ctx.device)].cpu().numpy()
+                c2, f2 = host.find_grid_corners_bits_batch(dense, self.H, self.W, self.min_area_ratio, 0.02, self.host_threads)
+                corners[over], found[over] = c2, f2
+                self.dense_fallbacks += int(over.size)
+            found = found.astype(bool)
+        elif self.packed:
             corners, found = host.find_grid_corners_bits_batch(self.pinned[slot][:m].numpy(), self.H, self.W, self.min_area_ratio, 0.02, self.host_threads)
         else:
             corners, found = host.find_grid_corners_batch(self.pinned[slot][:m].numpy(), self.min_area_ratio, 0.02, self.host_threads)
@@ -75,10 +131,13 @@ class FramePipeline:
         return corners, found & ok
 
     def describe(self):
-        d2h = (f"pinned D2H of the bit-packed binary ({self.H * self.W // 8 // 1000} KB/frame over PCIe)" if self.packed
+        d2h = (f"pinned D2H of sparse records of the bit-packed binary (row masks + non-zero words, {self.rec_bytes // 1000} KB/frame over PCIe, "
+               f"dense fallback {self.H * self.W // 8 // 1000} KB)" if self.sparse
+               else f"pinned D2H of the bit-packed binary ({self.H * self.W // 8 // 1000} KB/frame over PCIe)" if self.packed
                else f"pinned D2H of the binary ({self.H * self.W // 1000} KB/frame over PCIe)")
         return (f"K1 -> {'despeckle (exact speck filter) -> ' if self.despeckle else ''}{d2h} -> C++ contour corner search on "
-                f"{self.host_threads} host threads -> K2 -> K3, {self.chunk}-frame chunks triple-buffered")
+                f"{self.host_threads} host threads -> K2 -> K3, {self.chunk}-frame chunks, {self.depth} in flight"
+                + (f", host threads on the GPU's NUMA node ({len(self.cpus)} CPUs)" if self.cpus else ""))
 
     def run(self, frames, out=None, repeat=1):
         """frames u8 [n,H,W,3] on the context's device -> dict(digits u8[n,81], logits f32[n,81,10], conf f32[n,81],
@@ -96,10 +155,11 @@ class FramePipeline:
         found_all = np.zeros(n, bool)
         cur = torch.cuda.current_stream(dev)
         self.s_pre.wait_stream(cur)
+        self.s_d2h.wait_stream(cur)
         self.s_cls.wait_stream(cur)
         starts = [s0 for _ in range(repeat) for s0 in range(0, n, self.chunk)]
         pending = []                                  # (future, slot, start, m)
-        free_ev = [None, None, None]                  # classification done with slot's minv buffer
+        free_ev = [None] * self.depth                 # classification done with slot's buffers
 
         def classify(item):
             fut, slot, s, m = item
@@ -111,27 +171,35 @@ class FramePipeline:
                 self.ctx.frames_to_digits(frames[s:s + m], self.minv_dev[slot][:m], out=sub, glue=self.glue)
                 if not found.all():
                     out["digits"][s:s + m][torch.from_numpy(~found).to(dev)] = 0
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(blocking=True)      # the waiting thread sleeps instead of spinning: the box's CPU quota is for the search
                 ev.record(self.s_cls)
                 free_ev[slot] = ev
 
         for i, s in enumerate(starts):
-            slot = i % 3
+            slot = i % self.depth
             m = min(self.chunk, n - s)
             if free_ev[slot] is not None:
                 free_ev[slot].synchronize()
             with torch.cuda.stream(self.s_pre):
-                b = self.ctx.preprocess(frames[s:s + m])
-                # exact accelerator for the host search: erase the specks that cannot matter (csrc/k4_despeckle.hip)
+                # every buffer of a chunk belongs to its slot: an allocation in here (a 130-MB hipMalloc while the caching allocator's pool
+                # grows) stalls the whole pipeline for tens of milliseconds
+                b = self.ctx.preprocess(frames[s:s + m], out=self.dev_bin[slot][:m])
+                # exact accelerator for the host search: erase the specks that cannot matter (csrc/k4_despeckle.hip), in place
                 if self.packed:
-                    b = self.ctx.despeckle(b, out=self.dev_bin[slot][:m], packed=self.dev_bits[slot][:m])
+                    b = self.ctx.despeckle(b, out=b, packed=self.dev_bits[slot][:m])
+                    if self.sparse:
+                        b = self.ctx.pack_sparse_bits(b, self.dev_rec[slot])
                 elif self.despeckle:
-                    b = self.ctx.despeckle(b, out=self.dev_bin[slot][:m])
+                    b = self.ctx.despeckle(b, out=b)
+                ready = torch.cuda.Event()
+                ready.record(self.s_pre)
+            with torch.cuda.stream(self.s_d2h):
+                self.s_d2h.wait_event(ready)
                 self.pinned[slot][:m].copy_(b, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self.s_pre)
+                ev = torch.cuda.Event(blocking=True)      # the waiting thread sleeps instead of spinning: the box's CPU quota is for the search
+                ev.record(self.s_d2h)
             pending.append((self.pool.submit(self._search, slot, m, ev), slot, s, m))
-            if len(pending) > 1:
+            if len(pending) > self.depth - 2:
                 classify(pending.pop(0))
         while pending:
             classify(pending.pop(0))

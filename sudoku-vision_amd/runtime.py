@@ -154,6 +154,29 @@ class Context:
                                                     _stream_ptr()), "sv_despeckle_u8")
         return out if packed is None else packed
 
+    def pack_sparse_bits(self, bits, records):
+        """bits int32 [n,H,W//32] (despeckle's packed output) -> records uint8 [n,stride] (device): per frame the row masks of its
+        non-zero words and those words (sv_pack_sparse_bits; layout in include/sudoku_vision_hip.h).  A third to a quarter of the
+        dense image for the D2H copy; host.find_grid_corners_sparse_batch reads it."""
+        n, H, wpr = bits.shape
+        if records.dtype != torch.uint8 or records.dim() != 2 or records.shape[0] < n or not records.is_contiguous() or not bits.is_contiguous():
+            raise TypeError("records must be a contiguous uint8 [>=n, stride] device tensor")
+        _native.check(_native.lib().sv_pack_sparse_bits(self._h, _ptr(bits), n, H, wpr * 32, _ptr(records), records.shape[1], _stream_ptr()),
+                      "sv_pack_sparse_bits")
+        return records[:n]
+
+    def copy_to_pinned(self, src, dst):
+        """src (device tensor) -> dst (pinned host tensor of the same byte size) by a copy kernel on the current stream: about twice
+        the PCIe rate of the DMA engine tensor.copy_(non_blocking=True) uses (sv_copy_to_pinned_host).  Stream-ordered; synchronise
+        (an event, the stream) before reading dst."""
+        if not dst.is_pinned() or not dst.is_contiguous() or not src.is_contiguous():
+            raise TypeError("copy_to_pinned needs a contiguous device tensor and a contiguous pinned host tensor")
+        nbytes = src.numel() * src.element_size()
+        if nbytes != dst.numel() * dst.element_size():
+            raise ValueError("size mismatch")
+        _native.check(_native.lib().sv_copy_to_pinned_host(self._h, _ptr(src), _ptr(dst), nbytes, _stream_ptr()), "sv_copy_to_pinned_host")
+        return dst
+
     # ---- K2 -----------------------------------------------------------------------------------
     @staticmethod
     def corners_to_minv(corners, output_size=450, inset_ratio=0.0):

@@ -254,3 +254,70 @@ def test_small_frames_skip_the_speck_filter(ctx, golden_dir):
     assert sva.host.find_grid_corners(f[0]) is None or (sva.host.find_grid_corners(f[0]) == want[0]).all()
     big = FramePipeline(ctx, 1080, 1920, chunk=2, host_threads=1)
     assert big.despeckle and big.packed
+
+
+@pytest.mark.gpu
+def test_copy_to_pinned_host(ctx):
+    """sv_copy_to_pinned_host (the shader D2H copy of the end-to-end path): byte-exact for sizes with and without a 16-byte tail, ordered on
+    the stream, and a pageable destination is refused."""
+    g = torch.Generator().manual_seed(5)
+    for nbytes in (16, 48 + 7, 1 << 20, (1 << 20) + 3, 259200 * 3):
+        src = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, generator=g)
+        dev = src.to(ctx.device)
+        dst = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        ctx.copy_to_pinned(dev, dst)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src)
+    with pytest.raises(TypeError):
+        ctx.copy_to_pinned(dev, torch.zeros(nbytes, dtype=torch.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(1080, 1920), (270, 480), (96, 3648), (50, 4128)])
+def test_sparse_bit_records_kernel(ctx, H, W):
+    """sv_pack_sparse_bits against the numpy statement of the record format (tests/test_host_contours.py), empty to dense frames, with and
+    without overflow, one and two mask groups per row; and the records expand back to the dense image on the host."""
+    import sudoku_vision_amd as sva
+    from test_host_contours import _pack_sparse_np
+    rng = np.random.RandomState(H)
+    wpr = W // 32
+    imgs = np.stack([np.packbits(rng.rand(H, W) < d, axis=1, bitorder="little").view(np.uint32) for d in (0.0, 0.001, 0.01, 0.2, 1.0)])
+    imgs[4] = 0xFFFFFFFF
+    gpr = (wpr + 63) // 64
+    for cap in (H * wpr, H * wpr // 4, 4):
+        stride = sva.host.sparse_bits_record_bytes(H, W, cap)
+        rec = torch.full((len(imgs) + 1, stride), 0xEE, dtype=torch.uint8, device=ctx.device)
+        got = ctx.pack_sparse_bits(torch.from_numpy(imgs.view(np.int32)).to(ctx.device), rec).cpu().numpy()
+        assert (rec[len(imgs)].cpu().numpy() == 0xEE).all()                       # nothing written past the last record
+        for k in range(len(imgs)):
+            want = _pack_sparse_np(sva.host, imgs[k], cap)
+            nvals, cap_eff = (int(v) for v in want[:8].view(np.uint32))
+            used = 8 + 8 * H * gpr + 4 * min(nvals, cap_eff)
+            assert np.array_equal(got[k][:used], want[:used]), (H, W, cap, k)
+            assert (got[k][used:] == 0xEE).all()                                  # nor past a record's own values
+            if nvals <= cap_eff:
+                assert np.array_equal(sva.host.sparse_bits_expand(got[k], H, W), imgs[k])
+
+
+@pytest.mark.gpu
+def test_pipeline_sparse_handover_equals_dense(ctx):
+    """The end-to-end pipeline with the binary handed to the host search as sparse records, as the dense bit image, and with every record
+    forced to overflow (dense fallback per frame): identical corners, found flags and digits."""
+    from sudoku_vision_amd import synth
+    from sudoku_vision_amd.pipeline import FramePipeline
+    ctx.load_state_dict(synth.random_state_dict(1234))
+    frames = synth.synth_frames(6, 540, 960, seed=77, device=ctx.device)[0]
+    frames[2] = 90                                                               # no grid in this one
+    res = {}
+    for name, sparse in (("sparse", True), ("dense", False), ("overflow", 16)):
+        pipe = FramePipeline(ctx, 540, 960, chunk=4, host_threads=2, sparse=sparse)
+        assert pipe.sparse == (name != "dense")
+        out = pipe.run(frames)
+        torch.cuda.synchronize()
+        res[name] = (out["corners"].copy(), out["found"].copy(), out["digits"].cpu().numpy())
+        if name == "overflow":
+            assert pipe.dense_fallbacks == 5                                  # every frame but the flat one (no set pixels, nothing to overflow)
+    assert res["dense"][1].tolist() == [True, True, False, True, True, True]
+    for name in ("sparse", "overflow"):
+        for a, b in zip(res[name], res["dense"]):
+            assert np.array_equal(a, b), name

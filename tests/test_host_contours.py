@@ -179,3 +179,78 @@ def test_reference_photos_success_rate(host):
         assert (g is None) == (go is None) and (g is None or (g == go).all())
         found.append(g is not None)
     assert sum(found) == 4
+
+
+def _pack_sparse_np(host, bits, cap):
+    """numpy statement of the sparse record sv_pack_sparse_bits writes (include/sudoku_vision_hip.h)"""
+    H, wpr = bits.shape
+    gpr = (wpr + 63) // 64
+    nz = bits != 0
+    masks = np.zeros((H, gpr), np.uint64)
+    for g in range(gpr):
+        seg = nz[:, 64 * g:64 * g + 64]
+        masks[:, g] = (seg.astype(np.uint64) << np.arange(seg.shape[1], dtype=np.uint64)).sum(1, dtype=np.uint64)
+    vals = bits[nz].astype(np.uint32)
+    stride = host.sparse_bits_record_bytes(H, wpr * 32, cap)
+    cap = (stride - 8 - 8 * H * gpr) // 4                      # what fits in the (16-byte rounded) record is the capacity
+    rec = np.zeros(stride, np.uint8)
+    rec[:8] = np.array([vals.size, cap], np.uint32).view(np.uint8)
+    rec[8:8 + 8 * H * gpr] = masks.reshape(-1).view(np.uint8)
+    k = min(vals.size, cap)
+    rec[8 + 8 * H * gpr:8 + 8 * H * gpr + 4 * k] = vals[:k].view(np.uint8)
+    return rec
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (120, 1920), (40, 2752), (33, 4128)])
+def test_sparse_record_roundtrip_and_search(host, H, W):
+    """Host half of the sparse hand-over: a record expands to the dense image it was made from, the search on records equals the search on the
+    dense images, and a record that overflowed is reported (found == 2), not searched."""
+    rng = np.random.RandomState(H + W)
+    imgs = []
+    for density in (0.0, 0.02, 0.3):
+        b = (rng.rand(H, W) < density)
+        b[H // 8:H - H // 8, W // 8:W // 8 + 3] = True               # something large enough to be a contour
+        b[H // 8:H // 8 + 3, W // 8:W - W // 8] = True
+        imgs.append(np.packbits(b, axis=1, bitorder="little").view(np.uint32))
+    words = H * (W // 32)
+    recs = np.stack([_pack_sparse_np(host, b, words) for b in imgs])
+    for b, r in zip(imgs, recs):
+        assert np.array_equal(host.sparse_bits_expand(r, H, W), b)
+    c1, f1 = host.find_grid_corners_sparse_batch(recs, H, W, 0.01, 0.02, 2)
+    c2, f2 = host.find_grid_corners_bits_batch(np.stack(imgs), H, W, 0.01, 0.02, 2)
+    assert np.array_equal(f1.astype(bool), f2) and np.array_equal(c1, c2)
+    small = np.stack([_pack_sparse_np(host, b, 8) for b in imgs])
+    _, f3 = host.find_grid_corners_sparse_batch(small, H, W, 0.01, 0.02, 2)
+    assert (f3 == 2).all()
+    with pytest.raises(Exception):
+        host.sparse_bits_expand(small[0], H, W)
+
+
+def test_pool_affinity(host):
+    """sv_host_pool_set_affinity pins the library's worker threads (visible in /proc/self/task) and the search still gives the same answer;
+    the cpulist parser of pipeline.gpu_local_cpus."""
+    import os
+    from sudoku_vision_amd.pipeline import _parse_cpulist
+    assert _parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and _parse_cpulist("") == set()
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_getaffinity")
+    allowed = sorted(os.sched_getaffinity(0))
+    imgs = np.stack([_blobs(s, 96, 128) for s in range(6)])
+    ref = host.find_grid_corners_batch(imgs, 0.01, 0.02, 3)
+
+    def masks():
+        out = []
+        for t in os.listdir("/proc/self/task"):
+            for ln in open(f"/proc/self/task/{t}/status"):
+                if ln.startswith("Cpus_allowed_list:"):
+                    out.append(ln.split()[1])
+        return out
+
+    try:
+        host.set_pool_affinity([allowed[-1]])
+        got = host.find_grid_corners_batch(imgs, 0.01, 0.02, 3)
+        assert masks().count(str(allowed[-1])) >= 2                     # the two workers beside the calling thread
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    finally:
+        host.set_pool_affinity(allowed)
+    assert host._native.lib().sv_host_pool_set_affinity(None, 3) != 0          # SV_ERR_BAD_ARG

@@ -9,11 +9,11 @@
 // is < 2^-22 of the product).  What this does to the logits, measured against an exact (f64) evaluation of the same model on
 // the golden inputs: max error 1e-6, the same as PyTorch-CPU's own f32 forward (1.4e-6) -- tests/test_oracle_cnn.py holds the
 // simulation, tests/test_gpu_parity.py the measured kernel (<= 1e-4 is the contract, ~1e-6 is what comes out).
-// conv1, bias, ReLU, pooling, fc2 and the softmax stay in f32 on the VALU.
+// bias, ReLU, pooling, fc2 and the softmax stay in f32 on the VALU.
 //
-//   k_conv_features_h2 : persistent, one 512-thread workgroup per CU, producer waves (conv1 on the VALU) and consumer waves
-//        (conv2 on the matrix pipe) software-pipelined over cells with one barrier per cell; a producer and a consumer share
-//        each SIMD.  conv1 (f32 FMAs, a thread = one pooled pixel x 4 channels) writes its
+//   k_conv_features_h2 : persistent, one 512-thread workgroup per CU, producer waves (input staging, conv1) and consumer waves
+//        (conv2), both on the matrix pipe, software-pipelined over cells with one barrier per cell; a producer and a consumer
+//        share each SIMD.  conv1 is a GEMM over the 4x4 input patch of a pooling window (see the producer code); it writes its
 //        ReLU/pool output split into two f16 planes, channel-last (position-major, 32 channels = 64 B per position, rows padded
 //        against bank conflicts): one ds_read_b128 = one MFMA A operand (8 input channels of one 3x3 tap at one output
 //        position).  conv2 as an implicit GEMM: M = 4 pooling windows x 4 positions (so that the 4 accumulator registers of a

@@ -204,7 +204,7 @@ def main():
             budget //= world
         host_threads = max(1, min(16, budget) - 2)
         pipe = FramePipeline(ctx, H, W, chunk=next(c for c in (128, 64, 32, 16, 8, 4, 2, 1) if n % c == 0), host_threads=host_threads)
-        pipe.run(frames, out=out, repeat=2)           # warm-up (page-locks, thread start)
+        pipe.run(frames, out=out, repeat=max(2, args.e2e_passes))           # warm-up (page-locks, thread start, host caches)
         # three timed segments of e2e_passes passes each; the figure is their median and all three are reported: on a shared host a
         # segment now and then contains a 40-60 ms stall of one search call (tools/dev/search_outliers.py: about one call in 3000,
         # with or without GPU work in flight), which says nothing about the pipeline

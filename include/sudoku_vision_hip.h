@@ -111,6 +111,16 @@ int sv_adaptive_threshold_u8(sv_ctx *ctx, const uint8_t *src /*dev, n*H*W*/, int
 int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch,
                      ptrdiff_t img_stride, uint8_t *binary /*dev, n*H*W*/, void *stream);
 
+/* preprocess_for_grid_detection() with the binary written as 1 bit per pixel (bit = pixel != 0, LSB = leftmost, W/32
+ * words per row, rows dense): the form the host corner search reads (sv_find_grid_corners_bits_batch) when nothing
+ * else consumes the byte image.  Same pixels as sv_preprocess_u8.  Needs H, W >= 16, W % 32 == 0 and a 4-byte aligned
+ * frame layout (pitch, img_stride, bgr), else SV_ERR_UNSUPPORTED -- use sv_preprocess_u8 + sv_despeckle_u8(packed). */
+int sv_preprocess_bits_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch,
+                          ptrdiff_t img_stride, uint32_t *bits /*dev, n*H*W/32*/, void *stream);
+
+/* sv_despeckle_u8 on a bit image, in place (same filter, same precondition, same result as its `packed` output). */
+int sv_despeckle_bits(sv_ctx *ctx, uint32_t *bits /*dev, n*H*W/32*/, int n, int H, int W, void *stream);
+
 /* Accelerator for the host corner search, not a reference stage: erases every connected component of a {0,255}
  * image that lies strictly inside a 64x64 tile (two offset tile grids).  Such components can neither be nor
  * influence the result of find_grid_contour (argument in csrc/k4_despeckle.hip), so

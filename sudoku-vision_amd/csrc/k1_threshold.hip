@@ -113,6 +113,8 @@ __device__ __forceinline__ float lane_next(float v)   // value held by lane+1
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
+__device__ __forceinline__ u32 lane_next_u32(u32 v) { return __float_as_uint(lane_next(__uint_as_float(v))); }
+
 __device__ __forceinline__ float gray_f32(float b, float g, float r)
 {
     return floorf(__builtin_fmaf(b, 3735.f / 32768.f, __builtin_fmaf(g, 19235.f / 32768.f, __builtin_fmaf(r, 9798.f / 32768.f, 0.5f))));
@@ -293,6 +295,11 @@ constexpr int MARCH_STRIP = 240;   // output columns per wave
 // Requires W % 4 == 0 and 4-byte aligned rows (aligned4); other shapes use the tiled kernel.
 // Straight-line per-row body: no memory operation sits under a divergent or data-dependent branch, so the
 // compiler can keep PF row loads in flight (counted s_waitcnt vmcnt) instead of draining the queue.
+// BITS: the binary as 1 bit per pixel (LSB = leftmost, W/32 words per row; needs W % 32 == 0) -- what the host corner search reads in the
+// end-to-end pipeline, where nothing else consumes the byte image: 8x fewer store bytes here and a despeckle pass that reads 66 MB per 256
+// frames instead of 531.  A lane's 4 pixels are a nibble; 4 lanes' nibbles are gathered by lane shifts into 16-bit stores (a strip of 240
+// pixels starts on a 16-bit boundary).
+template <bool BITS>
 __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
                                                           u8 *__restrict__ out, Taps11 taps, int TH, int nstrips, int nbands, int nitems)
 {
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__
     if (item >= nitems) return;
     const int strip = item % nstrips, band = (item / nstrips) % nbands, frame = item / (nstrips * nbands);
     const u8 *img = bgr + (ptrdiff_t)frame * img_stride;
-    u8 *dst = out + (ptrdiff_t)frame * H * W;
+    u8 *dst = out + (ptrdiff_t)frame * H * (BITS ? W >> 3 : W);
 
     const int xs0 = strip * MARCH_STRIP - 8;
     const int cx0 = xs0 + 4 * lane;
@@ -407,9 +414,14 @@ __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__
 #pragma unroll
                         for (int j = 1; j <= 5; j++)
                             acc = __builtin_fmaf(__fadd_rn(win[(ph + NPH - 5 + j) % NPH][c], win[(ph + 2 * NPH - 5 - j) % NPH][c]), taps.k[5 + j], acc);
-                        o |= (__fsub_rn(rintf(acc), srcv[c]) >= 2.f ? 255u : 0u) << (8 * c);
+                        o |= (__fsub_rn(rintf(acc), srcv[c]) >= 2.f ? (BITS ? 1u : 255u) : 0u) << ((BITS ? 1 : 8) * c);
                     }
-                    if (lane >= 2 && lane < 62 && cx0 < W) *(u32 *)(dst + (ptrdiff_t)yo * W + cx0) = o;
+                    if (BITS) {
+                        const u32 a = o | (lane_next_u32(o) << 4);                     // lanes l, l+1
+                        const u32 w16 = a | (lane_next_u32(lane_next_u32(a)) << 8);    // lanes l .. l+3
+                        if (lane >= 2 && lane < 62 && ((lane - 2) & 3) == 0 && cx0 < W)
+                            *(unsigned short *)(dst + (ptrdiff_t)yo * (W >> 3) + (cx0 >> 3)) = (unsigned short)w16;
+                    } else if (lane >= 2 && lane < 62 && cx0 < W) *(u32 *)(dst + (ptrdiff_t)yo * W + cx0) = o;
                 }
             }
         }
@@ -482,6 +494,32 @@ __global__ void k_adaptive_threshold(const u8 *__restrict__ src, int H, int W, F
 
 }  // namespace
 
+// the march kernel's launch shape for n frames
+static void march_shape(int n, int H, int W, int &nstrips, int &nbands, int &TH)
+{
+    nstrips = (W + MARCH_STRIP - 1) / MARCH_STRIP;
+    nbands = (12288 + n * nstrips - 1) / (n * nstrips);      // ~3 rounds of 4 waves per SIMD on 256 CUs (flat between 4k and 20k waves)
+    if (nbands > H / 32) nbands = H / 32;
+    if (nbands < 1) nbands = 1;
+    TH = (H + nbands - 1) / nbands;
+    nbands = (H + TH - 1) / TH;
+}
+
+int svk_preprocess_bits(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint32_t *bits, hipStream_t s)
+{
+    if (H < 16 || W < 16 || (W & 31) || (pitch % 4) || (img_stride % 4) || ((uintptr_t)bgr % 4))
+        return sv_fail(SV_ERR_UNSUPPORTED, "sv_preprocess_bits_u8: needs H, W >= 16, W %% 32 == 0 and a 4-byte aligned frame layout");
+    Taps11 t;
+    sv_gaussian_taps_f32(11, t.k);
+    sv_time_scope ts(ctx, SVK_PREPROCESS, s);
+    int nstrips, nbands, TH;
+    march_shape(n, H, W, nstrips, nbands, TH);
+    const int nitems = n * nstrips * nbands;
+    hipLaunchKernelGGL(k_preprocess_march<true>, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, (u8 *)bits, t, TH, nstrips, nbands, nitems);
+    SV_LAUNCH_CHECK("k_preprocess_march<bits>");
+    return SV_OK;
+}
+
 int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s)
 {
     Taps11 t;
@@ -495,14 +533,10 @@ int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pi
         const int aligned4 = (pitch % 4 == 0) && (img_stride % 4 == 0) && (W % 4 == 0) && ((uintptr_t)bgr % 4 == 0) && ((uintptr_t)binary % 4 == 0);
         dim3 grid((W + FW - 1) / FW, (H + FH - 1) / FH, n);
         if (aligned4) {
-            const int nstrips = (W + MARCH_STRIP - 1) / MARCH_STRIP;
-            int nbands = (12288 + n * nstrips - 1) / (n * nstrips);      // ~3 rounds of 4 waves per SIMD on 256 CUs (flat between 8k and 16k waves)
-            if (nbands > H / 32) nbands = H / 32;
-            if (nbands < 1) nbands = 1;
-            const int TH = (H + nbands - 1) / nbands;
-            nbands = (H + TH - 1) / TH;
+            int nstrips, nbands, TH;
+            march_shape(n, H, W, nstrips, nbands, TH);
             const int nitems = n * nstrips * nbands;
-            hipLaunchKernelGGL(k_preprocess_march, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, TH, nstrips, nbands, nitems);
+            hipLaunchKernelGGL(k_preprocess_march<false>, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, TH, nstrips, nbands, nitems);
         } else {
             hipLaunchKernelGGL((k_preprocess_f32<64, 64, 512, 3, 2>), grid, dim3(512), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
         }

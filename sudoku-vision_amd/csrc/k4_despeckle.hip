@@ -109,6 +109,37 @@ __global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u
     }
 }
 
+// The same filter on a bit image, in place (1 bit per pixel, LSB = leftmost, wpr = W/32 words per row): a tile row is two words.  Tiles of
+// one pass are disjoint, so reading and writing the same array is safe within a pass.
+__global__ __launch_bounds__(256) void k_despeckle_bits(u32 *__restrict__ bits, int H, int wpr, int ox, int oy, int tiles_x, int tiles_y, long ntiles)
+{
+    const int lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+    const long frame = tile / ((long)tiles_x * tiles_y);
+    const int k0 = (tx * T - ox) >> 5, y = ty * T - oy + lane;        // first word of the tile row (-1 for the first tile of the offset grid)
+    const bool row_ok = y >= 0 && y < H;
+    u32 *row = bits + (frame * H + (row_ok ? y : 0)) * (long)wpr;
+    const bool ok0 = row_ok && k0 >= 0 && k0 < wpr, ok1 = row_ok && k0 + 1 < wpr;
+    const u64 f = (ok0 ? (u64)row[k0] : 0ull) | (ok1 ? (u64)row[k0 + 1] << 32 : 0ull);
+    const u64 ring = (lane == 0 || lane == T - 1) ? ~0ull : 0x8000000000000001ull;
+    u64 g = fill_runs(f, f & ring);
+    bool converged = false;
+    for (int it = 0; it < MAX_IT; it++) {
+        const u64 nb = g | lane_shift_up(g) | lane_shift_down(g);
+        const u64 seeds = f & (nb | (nb << 1) | (nb >> 1));          // 8-connectivity
+        const u64 g2 = fill_runs(f, g | seeds);
+        const bool changed = g2 != g;
+        g = g2;
+        if (!__any(changed)) { converged = true; break; }
+    }
+    const u64 keep = converged ? g : f;
+    if (keep == f) return;
+    if (ok0 && (u32)keep != (u32)f) row[k0] = (u32)keep;
+    if (ok1 && (u32)(keep >> 32) != (u32)(f >> 32)) row[k0 + 1] = (u32)(keep >> 32);
+}
+
 // Device -> mapped pinned host memory with plain 16-byte stores.  On this platform the shader's PCIe writes run at ~55 GB/s where
 // hipMemcpyAsync's DMA engine delivers 22-30 (tools/ubench_d2h.hip), and 64 small workgroups are enough to saturate the link.
 __global__ __launch_bounds__(256) void k_copy_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16, const u8 *__restrict__ tail_src,
@@ -168,6 +199,18 @@ __global__ __launch_bounds__(1024) void k_pack_sparse(const u32 *__restrict__ bi
 }
 
 }  // namespace
+
+int svk_despeckle_bits(uint32_t *bits, int n, int H, int W, hipStream_t s)
+{
+    for (int pass = 0; pass < 2; pass++) {
+        const int o = pass ? T / 2 : 0;
+        const int tiles_x = (W + o + T - 1) / T, tiles_y = (H + o + T - 1) / T;
+        const long ntiles = (long)n * tiles_x * tiles_y;
+        hipLaunchKernelGGL(k_despeckle_bits, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, bits, H, W >> 5, o, o, tiles_x, tiles_y, ntiles);
+        SV_LAUNCH_CHECK("k_despeckle_bits");
+    }
+    return SV_OK;
+}
 
 int svk_pack_sparse_bits(const u32 *bits, int n, int H, int W, u8 *records, long stride, hipStream_t s)
 {

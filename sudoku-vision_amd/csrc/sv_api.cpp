@@ -497,6 +497,21 @@ extern "C" int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, i
     return svk_preprocess(ctx, bgr, n, H, W, pitch, img_stride, binary, S(stream));
 }
 
+extern "C" int sv_preprocess_bits_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint32_t *bits, void *stream)
+{
+    REQUIRE(ctx && bgr && bits, "NULL argument");
+    REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
+    REQUIRE(((uintptr_t)bits & 3) == 0, "bits must be 4-byte aligned");
+    return svk_preprocess_bits(ctx, bgr, n, H, W, pitch, img_stride, bits, S(stream));
+}
+
+extern "C" int sv_despeckle_bits(sv_ctx *ctx, uint32_t *bits, int n, int H, int W, void *stream)
+{
+    REQUIRE(ctx && bits, "NULL argument");
+    REQUIRE(n > 0 && H > 0 && W > 0 && W % 32 == 0, "bad shape (W must be a multiple of 32)");
+    return svk_despeckle_bits(bits, n, H, W, S(stream));
+}
+
 extern "C" int sv_despeckle_u8(sv_ctx *ctx, const uint8_t *binary, int n, int H, int W, uint8_t *out, uint32_t *packed, void *stream)
 {
     REQUIRE(ctx && binary && out, "NULL argument");

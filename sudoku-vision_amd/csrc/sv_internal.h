@@ -82,6 +82,8 @@ int svk_blur(const u8 *src, int n, int H, int W, int ksize, u8 *dst, hipStream_t
 int svk_adaptive_threshold(const u8 *src, int n, int H, int W, int block, const float *taps, int idelta, int type_inv,
                            u8 *dst, hipStream_t s);
 int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s);
+int svk_preprocess_bits(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint32_t *bits, hipStream_t s);
+int svk_despeckle_bits(uint32_t *bits, int n, int H, int W, hipStream_t s);
 int svk_warp_perspective(const u8 *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size,
                          u8 *dst, hipStream_t s);
 int svk_extract_cells(const u8 *grid, int h, int w, ptrdiff_t pitch, int channels, int cell_size, int margin_h,

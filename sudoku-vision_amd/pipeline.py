@@ -64,7 +64,7 @@ def gpu_local_cpus(device):
 
 
 class FramePipeline:
-    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1, glue=0, despeckle=True, sparse=False, depth=5, cpu_affinity="auto"):
+    def __init__(self, ctx: Context, H: int, W: int, chunk: int = 32, host_threads=None, min_area_ratio=0.1, glue=0, despeckle=True, sparse=True, depth=5, cpu_affinity="auto", bits_direct=True):
         self.ctx, self.H, self.W, self.chunk = ctx, H, W, chunk
         # chunks in flight.  A chunk's chain is K1 -> D2H -> search -> K2/K3, and chunk i's K1 is only issued once chunk i-depth+1's search has
         # returned: with too few in flight the period is (K1 + D2H + search) / (depth - 1), not the slowest stage
@@ -81,10 +81,12 @@ class FramePipeline:
         self.s_cls = torch.cuda.Stream(dev)       # H2D + K2 + K3
         # D2H payload: with despeckle on and W % 32 == 0 the binary crosses PCIe as 1 bit per pixel (W/32 words per row)
         self.packed = self.despeckle and W % 32 == 0
-        # sparse=True: ... as sparse records (row masks + the non-zero words) with room for half of the words; a frame that does not fit is
-        # fetched dense (sv_pack_sparse_bits).  Off by default: it cuts the PCIe bytes 2-3x on the synthetic feed but costs a kernel, and on a
-        # one-GPU box the dense copy (0.30 ms per 64 frames at 55 GB/s) is not what bounds the pipeline (tools/e2e_breakdown.py); it is there for
-        # hosts where eight GPUs share the PCIe root and the host memory bandwidth
+        self.bits_direct = bool(bits_direct)        # K1 emits the bit image itself (sv_preprocess_bits_u8); False: byte image + packing despeckle
+        # sparse=True (default): ... as sparse records (row masks + the non-zero words) with room for half of the words; a frame that does not
+        # fit is fetched dense (sv_pack_sparse_bits).  2-3x fewer PCIe bytes on the synthetic feed for one small kernel; PCIe itself is not the
+        # bound (the dense copy runs at 55 GB/s on its own stream) but the host side is: the search threads then read 138 KB of records per
+        # frame instead of 259 KB of freshly DMA-written memory, and with K1 writing bits the pipeline is balanced enough for that to show
+        # (128-frame chunks: 132 k frames/s sparse, 113 k dense; tools/e2e_breakdown.py)
         self.sparse = self.packed and bool(sparse) and H * ((W // 32 + 63) // 64) <= 16000
         if self.packed:
             self.dev_bits = [torch.empty((chunk, H, W // 32), dtype=torch.int32, device=dev) for _ in range(depth)]
@@ -98,7 +100,7 @@ class FramePipeline:
             self.pinned = [torch.empty((chunk, H, W // 32), dtype=torch.int32).pin_memory() for _ in range(depth)]
         else:
             self.pinned = [torch.empty((chunk, H, W), dtype=torch.uint8).pin_memory() for _ in range(depth)]
-        self.dev_bin = [torch.empty((chunk, H, W), dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.dev_bin = None                       # byte images, only when K1 cannot write bits directly (allocated on first use)
         self.minv_pin = [torch.empty((chunk, 9), dtype=torch.float64).pin_memory() for _ in range(depth)]
         self.minv_dev = [torch.empty((chunk, 9), dtype=torch.float64, device=dev) for _ in range(depth)]
         # host threads next to the GPU: "auto" = the GPU's NUMA node, None = leave them alone, or an explicit set of CPUs.  Applies to the
@@ -135,7 +137,9 @@ class FramePipeline:
                f"dense fallback {self.H * self.W // 8 // 1000} KB)" if self.sparse
                else f"pinned D2H of the bit-packed binary ({self.H * self.W // 8 // 1000} KB/frame over PCIe)" if self.packed
                else f"pinned D2H of the binary ({self.H * self.W // 1000} KB/frame over PCIe)")
-        return (f"K1 -> {'despeckle (exact speck filter) -> ' if self.despeckle else ''}{d2h} -> C++ contour corner search on "
+        k1 = ("K1 (bit image) -> despeckle in place (exact speck filter) -> " if self.packed and self.bits_direct
+              else f"K1 -> {'despeckle (exact speck filter) -> ' if self.despeckle else ''}")
+        return (f"{k1}{d2h} -> C++ contour corner search on "
                 f"{self.host_threads} host threads -> K2 -> K3, {self.chunk}-frame chunks, {self.depth} in flight"
                 + (f", host threads on the GPU's NUMA node ({len(self.cpus)} CPUs)" if self.cpus else ""))
 
@@ -157,6 +161,11 @@ class FramePipeline:
         self.s_pre.wait_stream(cur)
         self.s_d2h.wait_stream(cur)
         self.s_cls.wait_stream(cur)
+        # sv_preprocess_bits_u8's layout requirements (otherwise K1 writes bytes and the despeckle packs them)
+        bits_direct = (self.packed and self.bits_direct and frames.is_contiguous() and frames.data_ptr() % 4 == 0 and (3 * self.W) % 4 == 0
+                       and self.H >= 16 and self.W >= 16)
+        if not bits_direct and self.dev_bin is None:
+            self.dev_bin = [torch.empty((self.chunk, self.H, self.W), dtype=torch.uint8, device=dev) for _ in range(self.depth)]
         starts = [s0 for _ in range(repeat) for s0 in range(0, n, self.chunk)]
         pending = []                                  # (future, slot, start, m)
         free_ev = [None] * self.depth                 # classification done with slot's buffers
@@ -183,10 +192,15 @@ class FramePipeline:
             with torch.cuda.stream(self.s_pre):
                 # every buffer of a chunk belongs to its slot: an allocation in here (a 130-MB hipMalloc while the caching allocator's pool
                 # grows) stalls the whole pipeline for tens of milliseconds
-                b = self.ctx.preprocess(frames[s:s + m], out=self.dev_bin[slot][:m])
+                if bits_direct:
+                    # K1 writes the bit image itself and the speck filter works on it in place: no byte image at all
+                    b = self.ctx.despeckle_bits(self.ctx.preprocess_bits(frames[s:s + m], out=self.dev_bits[slot][:m]))
+                else:
+                    b = self.ctx.preprocess(frames[s:s + m], out=self.dev_bin[slot][:m])
                 # exact accelerator for the host search: erase the specks that cannot matter (csrc/k4_despeckle.hip), in place
                 if self.packed:
-                    b = self.ctx.despeckle(b, out=b, packed=self.dev_bits[slot][:m])
+                    if not bits_direct:
+                        b = self.ctx.despeckle(b, out=b, packed=self.dev_bits[slot][:m])
                     if self.sparse:
                         b = self.ctx.pack_sparse_bits(b, self.dev_rec[slot])
                 elif self.despeckle:

@@ -144,6 +144,23 @@ class Context:
         _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
         return out
 
+    def preprocess_bits(self, frames, out=None):
+        """K1 with the binary as 1 bit per pixel: frames u8 [n,H,W,3] -> int32 [n,H,W//32] (LSB = leftmost pixel).  Needs W % 32 == 0 and
+        4-byte aligned rows (NativeError SV_ERR_UNSUPPORTED otherwise: use preprocess + despeckle(packed=...))."""
+        frames, pitch, fstride = _frame_layout(frames)
+        n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        if W % 32:
+            raise ValueError("preprocess_bits needs W % 32 == 0")
+        out = torch.empty((n, H, W // 32), dtype=torch.int32, device=self.device) if out is None else out
+        _native.check(_native.lib().sv_preprocess_bits_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_bits_u8")
+        return out
+
+    def despeckle_bits(self, bits):
+        """despeckle on a bit image int32 [n,H,W//32], in place."""
+        n, H, wpr = bits.shape
+        _native.check(_native.lib().sv_despeckle_bits(self._h, _ptr(bits), n, H, wpr * 32, _stream_ptr()), "sv_despeckle_bits")
+        return bits
+
     def despeckle(self, binary, out=None, packed=None):
         """binary u8 [n,H,W] in {0,255} -> the same with every component that fits strictly inside a 64x64 tile erased
         (find_grid_contour-equivalent; used only to make the host corner search cheaper).  packed: optional int32 [n,H,W//32]

@@ -210,16 +210,16 @@ def test_degenerate_quad_does_not_abort_the_batch(ctx, golden_dir, monkeypatch):
     # in the pipeline: the search's answer for frame 2 replaced by that quad (a rasterised diamond rarely ties exactly)
     ctx.load_state_dict(_trained(golden_dir))
     frames, corners, _ = _frames_cuda(4, 540, 960, 8)
-    real = sva.host.find_grid_corners_bits_batch
+    real = sva.host.find_grid_corners_sparse_batch
 
     def search(*a, **k):
         c, f = real(*a, **k)
         c[2] = bad.astype(np.int32)
         return c, f
 
-    monkeypatch.setattr(sva.host, "find_grid_corners_bits_batch", search)
+    monkeypatch.setattr(sva.host, "find_grid_corners_sparse_batch", search)
     pipe = FramePipeline(ctx, 540, 960, chunk=4, host_threads=2)
-    assert pipe.packed
+    assert pipe.packed and pipe.sparse
     res = pipe.run(frames)
     assert res["found"].tolist() == [True, True, False, True]
     assert (res["digits"][2] == 0).all()
@@ -321,3 +321,53 @@ def test_pipeline_sparse_handover_equals_dense(ctx):
     for name in ("sparse", "overflow"):
         for a, b in zip(res[name], res["dense"]):
             assert np.array_equal(a, b), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(1080, 1920), (540, 960), (33, 64), (200, 2752), (16, 32)])
+def test_bit_image_k1_and_despeckle(ctx, H, W):
+    """sv_preprocess_bits_u8 = the bits of sv_preprocess_u8's binary, and sv_despeckle_bits (in place) = sv_despeckle_u8's packed output, on a
+    synthetic frame, a noise frame and a flat one; the byte kernels are themselves bit-exact against the oracle elsewhere in this suite."""
+    from sudoku_vision_amd import synth
+    g = torch.Generator().manual_seed(H * W)
+    frames = torch.randint(0, 256, (3, H, W, 3), dtype=torch.uint8, generator=g)
+    if H >= 200:
+        frames[0] = torch.from_numpy(np.asarray(synth.synth_frames(1, H, W, seed=H, noise="int")[0][0]))
+    frames[2] = 77
+    frames = frames.to(ctx.device)
+    binary = ctx.preprocess(frames)
+    bits = ctx.preprocess_bits(frames)
+    want = np.packbits(binary.cpu().numpy() > 0, axis=2, bitorder="little").view(np.uint32).reshape(3, H, W // 32)
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), want)
+    packed = torch.empty_like(bits)
+    ctx.despeckle(binary, out=torch.empty_like(binary), packed=packed)
+    got = ctx.despeckle_bits(bits.clone())
+    assert torch.equal(got, packed)
+    assert want[2].sum() == 0                                                   # a flat frame thresholds to nothing
+
+
+@pytest.mark.gpu
+def test_pipeline_bit_image_path_equals_byte_path(ctx):
+    """FramePipeline with K1 writing the bit image directly (default) and with the byte image + packing despeckle: same corners, digits."""
+    from sudoku_vision_amd import synth
+    from sudoku_vision_amd.pipeline import FramePipeline
+    ctx.load_state_dict(synth.random_state_dict(1234))
+    frames = synth.synth_frames(6, 540, 960, seed=78, device=ctx.device)[0]
+    frames[4] = 30
+    res = []
+    for direct in (True, False):
+        pipe = FramePipeline(ctx, 540, 960, chunk=4, host_threads=2, bits_direct=direct)
+        assert ("bit image" in pipe.describe()) == direct
+        out = pipe.run(frames)
+        torch.cuda.synchronize()
+        res.append((out["corners"].copy(), out["found"].copy(), out["digits"].cpu().numpy()))
+    assert res[0][1].tolist() == [True, True, True, True, False, True]
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    # a view with padded rows is not contiguous: the pipeline falls back to the byte path by itself
+    wide = torch.zeros((6, 540, 992, 3), dtype=torch.uint8, device=ctx.device)
+    wide[:, :, :960] = frames
+    pipe = FramePipeline(ctx, 540, 960, chunk=4, host_threads=2)
+    out = pipe.run(wide[:, :, :960])
+    torch.cuda.synchronize()
+    assert pipe.dev_bin is not None and np.array_equal(out["corners"], res[0][0]) and np.array_equal(out["digits"].cpu().numpy(), res[0][2])

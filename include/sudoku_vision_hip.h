@@ -111,6 +111,20 @@ int sv_adaptive_threshold_u8(sv_ctx *ctx, const uint8_t *src /*dev, n*H*W*/, int
 int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch,
                      ptrdiff_t img_stride, uint8_t *binary /*dev, n*H*W*/, void *stream);
 
+/* sv_preprocess_u8 in its matrix-pipe formulation (csrc/k1_threshold_mm.hip: the four separable passes as Toeplitz GEMMs on the f16
+ * MFMA, the 11x11 float mean approximated and every pixel it cannot decide re-decided with cv2's exact sequence).  Same output, bit
+ * for bit; slower than the default kernel on MI355X (1.30 vs 0.64 ms per 256 1080p frames) -- an independent second implementation
+ * for cross-checking.  mean (optional, dev, n*H*W floats): the approximate local mean per pixel, for the tests' error measurement.
+ * Needs H, W >= 16, W % 16 == 0, 4-byte aligned frames, 16-byte aligned output: SV_ERR_UNSUPPORTED otherwise. */
+int sv_preprocess_mm_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
+                        uint8_t *binary /*dev, n*H*W*/, float *mean /*dev or NULL*/, void *stream);
+
+/* Diagnostics for sv_preprocess_mm_u8: the number of
+ * pixels, since the previous call, whose approximate local mean was too close to the threshold to decide and which were
+ * therefore decided with cv2's exact float sequence.  The first call on a context switches the counter on and returns 0.
+ * capacity: reserved (0).  Synchronises the device. */
+int sv_preprocess_stats(sv_ctx *ctx, unsigned *ambiguous, unsigned long *capacity);
+
 /* preprocess_for_grid_detection() with the binary written as 1 bit per pixel (bit = pixel != 0, LSB = leftmost, W/32
  * words per row, rows dense): the form the host corner search reads (sv_find_grid_corners_bits_batch) when nothing
  * else consumes the byte image.  Same pixels as sv_preprocess_u8.  Needs H, W >= 16, W % 32 == 0 and a 4-byte aligned

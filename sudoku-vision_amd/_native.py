@@ -30,6 +30,8 @@ SIGNATURES = {
     "sv_solve_sudoku": [_p, _p, _p],
     "sv_despeckle_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
     "sv_preprocess_bits_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
+    "sv_preprocess_stats": [_p, _p, _p],
+    "sv_preprocess_mm_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p],
     "sv_despeckle_bits": [_p, _p, _i, _i, _i, _p],
     "sv_copy_to_pinned_host": [_p, _p, _p, C.c_size_t, _p],
     "sv_sparse_bits_record_bytes": [_i, _i, _l],

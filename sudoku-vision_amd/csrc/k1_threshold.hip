@@ -12,6 +12,7 @@
 // then fma(below + above, k_j, s) outward), so the output is bit-identical to the CPU oracle.
 #include "sv_device.h"
 #include "sv_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -494,6 +495,10 @@ __global__ void k_adaptive_threshold(const u8 *__restrict__ src, int H, int W, F
 
 }  // namespace
 
+// SV_K1_ALGO: 0 (default) = the marching kernel, 1 = the matrix-pipe form (k1_threshold_mm.hip; same output, slower) where its layout
+// requirements hold
+static int k1_algo() { static const int a = [] { const char *e = getenv("SV_K1_ALGO"); return e ? atoi(e) : 0; }(); return a; }
+
 // the march kernel's launch shape for n frames
 static void march_shape(int n, int H, int W, int &nstrips, int &nbands, int &TH)
 {
@@ -509,6 +514,8 @@ int svk_preprocess_bits(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff
 {
     if (H < 16 || W < 16 || (W & 31) || (pitch % 4) || (img_stride % 4) || ((uintptr_t)bgr % 4))
         return sv_fail(SV_ERR_UNSUPPORTED, "sv_preprocess_bits_u8: needs H, W >= 16, W %% 32 == 0 and a 4-byte aligned frame layout");
+    if (k1_algo() == 1 && svk_preprocess_mm_supported(bgr, H, W, pitch, img_stride, bits, true))
+        return svk_preprocess_mm(ctx, bgr, n, H, W, pitch, img_stride, (u8 *)bits, true, nullptr, s);
     Taps11 t;
     sv_gaussian_taps_f32(11, t.k);
     sv_time_scope ts(ctx, SVK_PREPROCESS, s);
@@ -522,6 +529,8 @@ int svk_preprocess_bits(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff
 
 int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s)
 {
+    if (k1_algo() == 1 && svk_preprocess_mm_supported(bgr, H, W, pitch, img_stride, binary, false))
+        return svk_preprocess_mm(ctx, bgr, n, H, W, pitch, img_stride, binary, false, nullptr, s);
     Taps11 t;
     sv_gaussian_taps_f32(11, t.k);
     sv_time_scope ts(ctx, SVK_PREPROCESS, s);

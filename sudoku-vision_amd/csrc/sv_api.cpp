@@ -68,6 +68,7 @@ extern "C" int sv_ctx_destroy(sv_ctx *ctx)
     if (ctx->cells) (void)hipFree(ctx->cells);
     if (ctx->cells2) (void)hipFree(ctx->cells2);
     if (ctx->jpeg_planes) (void)hipFree(ctx->jpeg_planes);
+    if (ctx->k1_list) (void)hipFree(ctx->k1_list);
     for (auto &t : ctx->timeline) { (void)hipEventDestroy(t.t0); (void)hipEventDestroy(t.t1); }
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -495,6 +496,22 @@ extern "C" int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, i
     REQUIRE(ctx && bgr && binary, "NULL argument");
     REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
     return svk_preprocess(ctx, bgr, n, H, W, pitch, img_stride, binary, S(stream));
+}
+
+extern "C" int sv_preprocess_mm_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint8_t *binary, float *mean, void *stream)
+{
+    REQUIRE(ctx && bgr && binary, "NULL argument");
+    REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
+    if (!svk_preprocess_mm_supported(bgr, H, W, pitch, img_stride, binary, false))
+        return sv_fail(SV_ERR_UNSUPPORTED, "sv_preprocess_mm_u8: needs H, W >= 16, W %% 16 == 0, 4-byte aligned frames and a 16-byte aligned output");
+    return svk_preprocess_mm(ctx, bgr, n, H, W, pitch, img_stride, binary, false, mean, S(stream));
+}
+
+extern "C" int sv_preprocess_stats(sv_ctx *ctx, unsigned *ambiguous, unsigned long *capacity)
+{
+    REQUIRE(ctx && ambiguous && capacity, "NULL argument");
+    if (!ctx->k1_list) { *ambiguous = 0; *capacity = 0; return svk_preprocess_mm_enable_stats(ctx); }
+    return svk_preprocess_mm_stats(ctx, ambiguous, capacity);
 }
 
 extern "C" int sv_preprocess_bits_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint32_t *bits, void *stream)

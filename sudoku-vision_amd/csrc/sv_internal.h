@@ -43,6 +43,7 @@ struct sv_ctx {
     long cap_cells = 0;
     u8 *jpeg_planes = nullptr;  // decoded component planes (MCU-padded) between the IDCT and the colour kernel
     size_t cap_jpeg = 0;
+    void *k1_list = nullptr;    // k1_threshold_mm.hip: optional diagnostic counter (pixels decided by the exact evaluation), sv_preprocess_stats
     int precision = 0;          // SV_PREC_F32 / SV_PREC_BF16 (sv_ctx_set_precision)
     // optional per-kernel timing (sv_timing_begin/sv_timing_end): hipEvents on the launch stream
     bool timing = false;
@@ -84,6 +85,10 @@ int svk_adaptive_threshold(const u8 *src, int n, int H, int W, int block, const 
 int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s);
 int svk_preprocess_bits(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint32_t *bits, hipStream_t s);
 int svk_despeckle_bits(uint32_t *bits, int n, int H, int W, hipStream_t s);
+int svk_preprocess_mm_stats(sv_ctx *ctx, unsigned *ambiguous, unsigned long *capacity);
+int svk_preprocess_mm_enable_stats(sv_ctx *ctx);
+bool svk_preprocess_mm_supported(const u8 *bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, const void *out, bool bits);
+int svk_preprocess_mm(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *out, bool bits, float *mean_dbg, hipStream_t s);
 int svk_warp_perspective(const u8 *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size,
                          u8 *dst, hipStream_t s);
 int svk_extract_cells(const u8 *grid, int h, int w, ptrdiff_t pitch, int channels, int cell_size, int margin_h,

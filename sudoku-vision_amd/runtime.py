@@ -144,6 +144,24 @@ class Context:
         _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
         return out
 
+    def preprocess_mm(self, frames, want_mean=False):
+        """preprocess() through the matrix-pipe formulation of K1 (sv_preprocess_mm_u8): the same binary, an independent implementation.
+        want_mean: also return the kernel's approximate local mean per pixel (f32 [n,H,W])."""
+        frames, pitch, fstride = _frame_layout(frames)
+        n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
+        mean = torch.zeros((n, H, W), dtype=torch.float32, device=self.device) if want_mean else None
+        _native.check(_native.lib().sv_preprocess_mm_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _ptr(mean) if want_mean else None,
+                                                        _stream_ptr()), "sv_preprocess_mm_u8")
+        return (out, mean) if want_mean else out
+
+    def preprocess_stats(self):
+        """(pixels decided by the exact evaluation in preprocess_mm launches since the last call, 0); the first call switches the counter on.
+        Synchronises."""
+        a, c = C.c_uint(), C.c_ulong()
+        _native.check(_native.lib().sv_preprocess_stats(self._h, C.byref(a), C.byref(c)), "sv_preprocess_stats")
+        return a.value, c.value
+
     def preprocess_bits(self, frames, out=None):
         """K1 with the binary as 1 bit per pixel: frames u8 [n,H,W,3] -> int32 [n,H,W//32] (LSB = leftmost pixel).  Needs W % 32 == 0 and
         4-byte aligned rows (NativeError SV_ERR_UNSUPPORTED otherwise: use preprocess + despeckle(packed=...))."""

@@ -574,3 +574,34 @@ def test_padded_rows_and_frame_gaps(ctx, golden_dir, row_pad, frame_gap):
     a, b = ctx.frames_to_digits(view, minv), ctx.frames_to_digits(dense, minv)
     assert torch.equal(a["digits"], b["digits"]) and torch.equal(a["logits"], b["logits"])
     assert (ctx.preprocess(dense)[0].cpu().numpy() == o.preprocess_for_grid_detection(dense[0].cpu().numpy())).all()
+
+
+@pytest.mark.parametrize("H,W,kind", [(1080, 1920, "synthetic"), (1080, 1920, "noise"), (540, 960, "synthetic"), (64, 128, "noise"), (33, 48, "noise"),
+                                      (100, 272, "noise"), (16, 16, "noise"), (200, 144, "flat")])
+def test_k1_matrix_pipe_form(ctx, H, W, kind):
+    """K1 in its second, independent formulation (csrc/k1_threshold_mm.hip: Toeplitz GEMMs on the f16 MFMA, approximate local mean, exact
+    re-decision of the pixels the approximation cannot decide) against the oracle, bit for bit; and the approximation error the scheme's
+    EPS = 2^-9 rests on, measured against a float64 evaluation of the same Gaussian on the oracle's blurred image."""
+    from scipy import ndimage
+    if kind == "synthetic":
+        frames = _frames(2, H, W, seed=H + W)[0]
+    elif kind == "noise":
+        frames = torch.randint(0, 256, (2, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(H * W)).to(ctx.device)
+        frames[1] = (frames[1].float() * 0.1 + 100).to(torch.uint8)               # low-contrast noise: many means close to src + 1.5
+    else:
+        frames = torch.full((2, H, W, 3), 90, dtype=torch.uint8, device=ctx.device)
+        frames[1, :, : W // 2] = 97
+    ctx.preprocess_stats()                                                        # switches the counter on / resets it
+    binary, mean = ctx.preprocess_mm(frames, want_mean=True)
+    redecided, _ = ctx.preprocess_stats()
+    host = frames.cpu().numpy()
+    taps = o.gaussian_kernel_f32(11).astype(np.float64)
+    worst = 0.0
+    for i in range(2):
+        assert (binary[i].cpu().numpy() == o.preprocess_for_grid_detection(host[i])).all(), (H, W, kind, i)
+        blurred = o.gaussian_blur(o.gray(host[i]), 5).astype(np.float64)
+        ref = ndimage.correlate1d(ndimage.correlate1d(blurred, taps, axis=1, mode="nearest"), taps, axis=0, mode="nearest")
+        worst = max(worst, float(np.abs(mean[i].cpu().numpy().astype(np.float64) - ref).max()))
+    assert worst < 4e-4, worst                   # the float64 sum is itself within 1.5e-4 of cv2's float chain; EPS is 1.95e-3
+    assert torch.equal(binary, ctx.preprocess(frames))
+    assert redecided < 0.02 * 2 * H * W + 64, redecided

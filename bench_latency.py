@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2]: one camera feed at 30 fps, per-frame latency of the hot path on one MI355X.
 
-Per frame:  pinned host frame --H2D--> K1 -> despeckle --D2H binary--> host contour corner search --> Minv --H2D--> K2 -> K3
+Per frame:  pinned host frame --H2D--> K1 (bit image) -> despeckle --D2H bits--> host contour corner search --> Minv --H2D--> K2 -> K3
             --D2H--> 81 digits.   The two device segments (K1; K2->K3) are hipGraph-captured once and replayed.
 Reports p50/p90/p99 of (a) the whole frame -> digits latency as a host clock around it, (b) its device segments.
 Prints one JSON line.  Not the headline metric (that is bench.py)."""
@@ -54,7 +54,7 @@ def main():
         stream.synchronize()
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, stream=stream):
-            ctx.despeckle(ctx.preprocess(frame_d), out=binary_d, packed=bits_d)
+            ctx.despeckle_bits(ctx.preprocess_bits(frame_d, out=bits_d))     # K1 writes the bit image, the speck filter works on it in place
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, stream=stream):
             ctx.frames_to_digits(frame_d, minv_d, out=out, glue=args.glue)

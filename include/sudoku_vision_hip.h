@@ -69,12 +69,13 @@ int sv_ctx_set_precision(sv_ctx *ctx, int precision);
 int sv_ctx_reserve(sv_ctx *ctx, long max_cells);
 
 /* Measurement aid (no reference counterpart; pipeline/run.py:247-352 uses time.time()).  Between
- * sv_timing_begin and sv_timing_end every launch of the four hot kernels is bracketed by hipEvents on
+ * sv_timing_begin and sv_timing_end every launch of the hot kernels is bracketed by hipEvents on
  * the stream it is launched on.  sv_timing_end waits for those events and returns, per kernel id
- * 0 = preprocess, 1 = warp_cells, 2 = conv_features, 3 = fc_head: total milliseconds and launches. */
-#define SV_TIMED_KERNELS 4
+ * 0 = preprocess, 1 = warp_cells, 2 = conv_features, 3 = fc_head, 4 = the fused preprocess + warp_cells launch: total
+ * milliseconds and launches. */
+#define SV_TIMED_KERNELS 5
 int sv_timing_begin(sv_ctx *ctx);
-int sv_timing_end(sv_ctx *ctx, double *ms_total /*host, 4*/, long *launches /*host, 4*/);
+int sv_timing_end(sv_ctx *ctx, double *ms_total /*host, SV_TIMED_KERNELS*/, long *launches /*host, SV_TIMED_KERNELS*/);
 
 /* Measurement aid: which conv/fc kernels sv_cnn_forward_* / sv_frames_to_digits launch in this process (SV_CONV_ALGO environment
  * variable; default 4 = f16 hi/lo operand pairs on the f16 matrix pipe, csrc/k3_cnn_h2.hip) and the matrix instructions they
@@ -118,6 +119,14 @@ int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int 
  * Needs H, W >= 16, W % 16 == 0, 4-byte aligned frames, 16-byte aligned output: SV_ERR_UNSUPPORTED otherwise. */
 int sv_preprocess_mm_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
                         uint8_t *binary /*dev, n*H*W*/, float *mean /*dev or NULL*/, void *stream);
+
+/* BASELINE configs[4], "fused threshold/warp" for the device-only mode: preprocess_for_grid_detection (cv/preprocess.py:57-65) and
+ * warp_perspective + extract_cells (cv/grid.py:94-133, cv/extract.py:13-56) of the same frames in ONE launch, for callers that know the
+ * corners before thresholding (a tracker, the benchmark's generator corners).  Same outputs as sv_preprocess_u8 + sv_warp_cells_u8.
+ * The grid places everything that reads frame f on the same XCD at the same time, so the two stages share the frame's bytes in L2.
+ * Needs H, W >= 16, W % 4 == 0 and 4-byte aligned frames / binary: SV_ERR_UNSUPPORTED otherwise. */
+int sv_preprocess_warp_cells_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
+                                uint8_t *binary /*dev, n*H*W*/, const double *minv /*dev, n*9*/, uint8_t *cells /*dev, n*81*784*/, void *stream);
 
 /* Diagnostics for sv_preprocess_mm_u8: the number of
  * pixels, since the previous call, whose approximate local mean was too close to the threshold to decide and which were

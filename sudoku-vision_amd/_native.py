@@ -31,6 +31,7 @@ SIGNATURES = {
     "sv_despeckle_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
     "sv_preprocess_bits_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
     "sv_preprocess_stats": [_p, _p, _p],
+    "sv_preprocess_warp_cells_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p, _p],
     "sv_preprocess_mm_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p],
     "sv_despeckle_bits": [_p, _p, _i, _i, _i, _p],
     "sv_copy_to_pinned_host": [_p, _p, _p, C.c_size_t, _p],

@@ -12,6 +12,7 @@
 // then fma(below + above, k_j, s) outward), so the output is bit-identical to the CPU oracle.
 #include "sv_device.h"
 #include "sv_internal.h"
+#include "k2_cells_body.h"
 #include <cstdlib>
 
 namespace {
@@ -300,16 +301,12 @@ constexpr int MARCH_STRIP = 240;   // output columns per wave
 // end-to-end pipeline, where nothing else consumes the byte image: 8x fewer store bytes here and a despeckle pass that reads 66 MB per 256
 // frames instead of 531.  A lane's 4 pixels are a nibble; 4 lanes' nibbles are gathered by lane shifts into 16-bit stores (a strip of 240
 // pixels starts on a 16-bit boundary).
+// One (frame, band, strip) item = the work of one wave; sdl = that wave's delay line of blurred rows in LDS.
 template <bool BITS>
-__global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
-                                                          u8 *__restrict__ out, Taps11 taps, int TH, int nstrips, int nbands, int nitems)
+__device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *__restrict__ out,
+                                           const Taps11 &taps, int TH, int nstrips, int nbands, int item, f32x4_t (*sdl)[64])
 {
-    __shared__ __attribute__((aligned(16))) f32x4_t sdl[4][8][64];   // per-wave delay line of blurred rows
-
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= nitems) return;
     const int strip = item % nstrips, band = (item / nstrips) % nbands, frame = item / (nstrips * nbands);
     const u8 *img = bgr + (ptrdiff_t)frame * img_stride;
     u8 *dst = out + (ptrdiff_t)frame * H * (BITS ? W >> 3 : W);
@@ -404,10 +401,10 @@ __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__
                     for (int k = 0; k < NPH; k++) win[k] = cur_rw;   // top REPLICATE: rows above the first one read the first one
                 }
                 win[ph] = cur_rw;
-                sdl[wave][i & 7][lane] = cur_bf;
+                sdl[i & 7][lane] = cur_bf;
                 if (i >= emit_from) {                            // emit output row yo; its window centre was pushed 5 pushes ago
                     const int yo = q - 5;
-                    const f32x4_t srcv = sdl[wave][(i - 5) & 7][lane];
+                    const f32x4_t srcv = sdl[(i - 5) & 7][lane];
                     u32 o = 0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
@@ -426,6 +423,38 @@ __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__
                 }
             }
         }
+    }
+}
+
+template <bool BITS>
+__global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
+                                                          u8 *__restrict__ out, Taps11 taps, int TH, int nstrips, int nbands, int nitems)
+{
+    __shared__ __attribute__((aligned(16))) f32x4_t sdl[4][8][64];   // per-wave delay line of blurred rows
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= nitems) return;
+    march_item<BITS>(bgr, H, W, pitch, img_stride, out, taps, TH, nstrips, nbands, item, sdl[wave]);
+}
+
+// BASELINE configs[4]'s fused threshold + warp launch for the device-only mode (corners known before K1 runs, so K1 and K2 are independent
+// and both read the frame): one grid holds the marching items and the (frame, cell) workgroups of K2 (sv_k2::warp_cells_item, the very code
+// k_warp_cells runs), laid out so that everything that touches frame f is dispatched together and on the same XCD (workgroup b runs on XCD
+// b % 8; frame f belongs to XCD f % 8) -- whichever of the two reads a frame region first leaves it in that XCD's L2 for the other.
+__global__ __launch_bounds__(256) void k_preprocess_warp_fused(const u8 *__restrict__ bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
+                                                               u8 *__restrict__ out, Taps11 taps, int TH, int nstrips, int nbands,
+                                                               const double *__restrict__ minv, u8 *__restrict__ cells)
+{
+    __shared__ __attribute__((aligned(16))) f32x4_t sdl[4][8][64];
+    __shared__ sv_k2::CellsLds cl;
+    const int items = nstrips * nbands, k1_wgs = (items + 3) / 4, per_frame = k1_wgs + 81;
+    const int j = blockIdx.x >> 3, frame = (j / per_frame) * 8 + (blockIdx.x & 7), within = j % per_frame;
+    if (frame >= n) return;
+    if (within < k1_wgs) {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), local = within * 4 + wave;
+        if (local < items) march_item<false>(bgr, H, W, pitch, img_stride, out, taps, TH, nstrips, nbands, frame * items + local, sdl[wave]);
+    } else {
+        sv_k2::warp_cells_item(bgr, H, W, pitch, img_stride, minv, cells, frame, within - k1_wgs, cl);
     }
 }
 
@@ -524,6 +553,23 @@ int svk_preprocess_bits(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff
     const int nitems = n * nstrips * nbands;
     hipLaunchKernelGGL(k_preprocess_march<true>, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, (u8 *)bits, t, TH, nstrips, nbands, nitems);
     SV_LAUNCH_CHECK("k_preprocess_march<bits>");
+    return SV_OK;
+}
+
+int svk_preprocess_warp_fused(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, const double *minv, u8 *cells,
+                              hipStream_t s)
+{
+    if (H < 16 || W < 16 || (W & 3) || (pitch % 4) || (img_stride % 4) || ((uintptr_t)bgr % 4) || ((uintptr_t)binary % 4))
+        return sv_fail(SV_ERR_UNSUPPORTED, "sv_preprocess_warp_cells_u8: needs H, W >= 16, W %% 4 == 0 and a 4-byte aligned layout");
+    Taps11 t;
+    sv_gaussian_taps_f32(11, t.k);
+    sv_time_scope ts(ctx, SVK_FUSED12, s);
+    int nstrips, nbands, TH;
+    march_shape(n, H, W, nstrips, nbands, TH);
+    const long per_frame = (nstrips * nbands + 3) / 4 + 81;
+    const long blocks = (long)((n + 7) / 8) * per_frame * 8;
+    hipLaunchKernelGGL(k_preprocess_warp_fused, dim3((unsigned)blocks), dim3(256), 0, s, bgr, n, H, W, pitch, img_stride, binary, t, TH, nstrips, nbands, minv, cells);
+    SV_LAUNCH_CHECK("k_preprocess_warp_fused");
     return SV_OK;
 }
 

@@ -498,6 +498,14 @@ extern "C" int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, i
     return svk_preprocess(ctx, bgr, n, H, W, pitch, img_stride, binary, S(stream));
 }
 
+extern "C" int sv_preprocess_warp_cells_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint8_t *binary,
+                                           const double *minv, uint8_t *cells, void *stream)
+{
+    REQUIRE(ctx && bgr && binary && minv && cells, "NULL argument");
+    REQUIRE(n > 0 && n < 65536 && H > 0 && W > 0 && pitch >= 3 * (ptrdiff_t)W, "bad shape");
+    return svk_preprocess_warp_fused(ctx, bgr, n, H, W, pitch, img_stride, binary, minv, cells, S(stream));
+}
+
 extern "C" int sv_preprocess_mm_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint8_t *binary, float *mean, void *stream)
 {
     REQUIRE(ctx && bgr && binary, "NULL argument");

@@ -52,7 +52,7 @@ struct sv_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 
-enum sv_kernel_id { SVK_PREPROCESS = 0, SVK_WARP_CELLS = 1, SVK_CONV_FEATURES = 2, SVK_FC_HEAD = 3, SVK_COUNT = 4 };
+enum sv_kernel_id { SVK_PREPROCESS = 0, SVK_WARP_CELLS = 1, SVK_CONV_FEATURES = 2, SVK_FC_HEAD = 3, SVK_FUSED12 = 4, SVK_COUNT = 5 };
 
 // RAII bracket: records an event before and after a launch when ctx->timing is on
 struct sv_time_scope {
@@ -89,6 +89,8 @@ int svk_preprocess_mm_stats(sv_ctx *ctx, unsigned *ambiguous, unsigned long *cap
 int svk_preprocess_mm_enable_stats(sv_ctx *ctx);
 bool svk_preprocess_mm_supported(const u8 *bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, const void *out, bool bits);
 int svk_preprocess_mm(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *out, bool bits, float *mean_dbg, hipStream_t s);
+int svk_preprocess_warp_fused(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, const double *minv, u8 *cells,
+                              hipStream_t s);
 int svk_warp_perspective(const u8 *img, int H, int W, ptrdiff_t pitch, int channels, const double *minv, int out_size,
                          u8 *dst, hipStream_t s);
 int svk_extract_cells(const u8 *grid, int h, int w, ptrdiff_t pitch, int channels, int cell_size, int margin_h,

@@ -86,15 +86,15 @@ class Context:
         _native.check(_native.lib().sv_ctx_reserve(self._h, int(max_cells)), "sv_ctx_reserve")
 
     # ---- per-kernel timing (hipEvents on the launch stream, inside the library) -------------------
-    KERNELS = ("k_preprocess", "k_warp_cells", "k_conv_features", "k_fc_head")
+    KERNELS = ("k_preprocess", "k_warp_cells", "k_conv_features", "k_fc_head", "k_preprocess_warp_fused")
 
     def timing_begin(self):
         _native.check(_native.lib().sv_timing_begin(self._h), "sv_timing_begin")
 
     def timing_end(self):
         """-> {kernel name: (total ms, launches)}; waits for the recorded events."""
-        ms = (C.c_double * 4)()
-        cnt = (C.c_long * 4)()
+        ms = (C.c_double * len(self.KERNELS))()
+        cnt = (C.c_long * len(self.KERNELS))()
         _native.check(_native.lib().sv_timing_end(self._h, ms, cnt), "sv_timing_end")
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNELS)}
 
@@ -143,6 +143,17 @@ class Context:
             raise TypeError("out must be a contiguous uint8 tensor of shape [n,H,W]")
         _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
         return out
+
+    def preprocess_and_warp_cells(self, frames, minv_dev, binary=None, cells=None):
+        """K1 and K2 of the same frames in one launch (sv_preprocess_warp_cells_u8; BASELINE configs[4]'s fused threshold/warp for callers
+        that know the corners beforehand) -> (binary u8 [n,H,W], cells u8 [n,81,28,28])."""
+        frames, pitch, fstride = _frame_layout(frames)
+        n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        binary = torch.empty((n, H, W), dtype=torch.uint8, device=self.device) if binary is None else binary
+        cells = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device) if cells is None else cells
+        _native.check(_native.lib().sv_preprocess_warp_cells_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(binary), _ptr(minv_dev), _ptr(cells),
+                                                                _stream_ptr()), "sv_preprocess_warp_cells_u8")
+        return binary, cells
 
     def preprocess_mm(self, frames, want_mean=False):
         """preprocess() through the matrix-pipe formulation of K1 (sv_preprocess_mm_u8): the same binary, an independent implementation.

@@ -381,3 +381,20 @@ def test_pipeline_bit_image_path_equals_byte_path(ctx):
     out = pipe.run(wide[:, :, :960])
     torch.cuda.synchronize()
     assert pipe.dev_bin is not None and np.array_equal(out["corners"], res[0][0]) and np.array_equal(out["digits"].cpu().numpy(), res[0][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,H,W", [(9, 540, 960), (3, 1080, 1920), (1, 64, 96)])
+def test_fused_threshold_warp_launch(ctx, n, H, W):
+    """BASELINE configs[4]'s fused threshold + warp (sv_preprocess_warp_cells_u8: K1 and K2 of the same frames in one launch, frame-to-XCD
+    affinity) gives exactly what the two separate launches give; frame counts that do not fill the 8-XCD layout included."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd import synth
+    frames, corners, _ = synth.synth_frames(n, H, W, seed=n + H, device=ctx.device)
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners).reshape(n, 9))
+    binary, cells = ctx.preprocess_and_warp_cells(frames, minv)
+    assert torch.equal(binary, ctx.preprocess(frames))
+    assert torch.equal(cells, ctx.warp_cells(frames, minv))
+    host = frames[0].cpu().numpy()
+    assert (binary[0].cpu().numpy() == o.preprocess_for_grid_detection(host)).all()
+    assert (cells[0].cpu().numpy() == o.warp_cells(host, corners[0])).all()

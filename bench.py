@@ -292,7 +292,9 @@ def main():
             "kernels": kernels,
             "pipeline_hbm_frac": fps / world * BYTES_PER_FRAME / HBM_PEAK,
             "end_to_end_with_host_corner_search": e2e,
-            "pipeline_fp32_frac": fps / world * 81 * (CONV_FLOP_PER_CELL + FC_FLOP_PER_CELL) / FP32_MFMA_PEAK,
+            # whole-step view of the CNN's ALGORITHMIC (f32-equivalent) FLOPs against the f32 MFMA peak -- a context figure, not a roofline
+            # fraction: the default kernels do this arithmetic on the f16 pipe (their own fractions are in "kernels", priced on issued FLOPs)
+            "pipeline_algorithmic_cnn_flops_vs_f32_mfma_peak": fps / world * 81 * (CONV_FLOP_PER_CELL + FC_FLOP_PER_CELL) / FP32_MFMA_PEAK,
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)

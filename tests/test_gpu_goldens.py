@@ -89,6 +89,16 @@ def test_all_reference_photos_end_to_end(ctx, golden_dir, rec):
     assert (np.stack(res.cells) == P[key + "_cells"]).all()                # run_pipeline: warp 450x450 then extract_cells = the fused K2
     assert [p.digit if p.is_original else 0 for p in res.predictions] == P[key + "_digits"].tolist()
     assert res.recognized_grid == [[int(P[key + "_digits"][r * 9 + c]) for c in range(9)] for r in range(9)]
+    # the batched pipeline on the same photo (portrait photos are 2736 wide: not a multiple of 32, so the byte image + byte search path;
+    # landscape ones take the bit-image path): same corners, same digits
+    from sudoku_vision_amd.pipeline import FramePipeline
+    H, W = frame.shape[0], frame.shape[1]
+    pipe = FramePipeline(ctx, H, W, chunk=1, host_threads=2, glue=ctx.GLUE_RUNPY)
+    assert pipe.packed == (W % 32 == 0)
+    pres = pipe.run(frame[None].contiguous())
+    torch.cuda.synchronize()
+    assert pres["found"].tolist() == [True] and (pres["corners"][0] == corners).all()
+    assert (pres["digits"][0].cpu().numpy() == P[key + "_digits"]).all()
 
 
 def test_hipgraph_capture_replay_configs2(ctx, golden_dir):

@@ -23,8 +23,9 @@ H, W, CH = 1080, 1920, int(sys.argv[2]) if len(sys.argv) > 2 else 64
 DEPTH = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 
 
-def gpu_ms(fn, reps=10):
-    fn()
+def gpu_ms(fn, reps=30):
+    for _ in range(30):                     # the chip needs tens of milliseconds of load to reach its sustained clock
+        fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

@@ -234,7 +234,9 @@ class BorderScanner {
 // border cost nothing.  Same borders, same points, same order as BorderScanner (tests/test_host_contours.py compares them).
 class BitScanner {
   public:
-    BitScanner(const uint32_t *bits, int H, int W) : b_(bits), h_(H), w_(W), wpr_(W >> 5)
+    // rowmask (optional): per row and group of 64 words, bit k = word 64g + k of the row is non-zero (the sparse record's masks): the raster
+    // scan then steps from one non-zero word to the next instead of testing every word, and skips empty rows outright
+    BitScanner(const uint32_t *bits, int H, int W, const uint64_t *rowmask = nullptr) : b_(bits), h_(H), w_(W), wpr_(W >> 5), rm_(rowmask), gpr_(((W >> 5) + 63) / 64)
     {
         Planes &tl = planes();
         const size_t words = (size_t)H * wpr_;
@@ -261,6 +263,18 @@ class BitScanner {
         for (int y = 0; y < h_; y++) {
             const uint32_t *brow = b_ + (size_t)y * wpr_;
             const uint32_t *trow = t_ + (size_t)y * wpr_, *rrow = r_ + (size_t)y * wpr_;
+            const uint64_t *rm = rm_ ? rm_ + (size_t)y * gpr_ : nullptr;
+            // first word >= k that has a set pixel (labels only ever sit on set pixels), or wpr_
+            auto next_word = [&](int k) -> int {
+                if (!rm) { while (k < wpr_ && !brow[k]) k++; return k; }
+                while (k < wpr_) {
+                    const uint64_t m = rm[k >> 6] >> (k & 63);
+                    if (m) return k + __builtin_ctzll(m);
+                    k = (k | 63) + 1;
+                }
+                return wpr_;
+            };
+            if (next_word(0) >= wpr_) continue;                   // empty row
             bool inside = false;                                  // the last label passed on this row is positive
             int x = 0;
             for (;;) {
@@ -273,10 +287,9 @@ class BitScanner {
                         const uint32_t e = (trow[k] | (bw & ~((bw << 1) | (k ? brow[k - 1] >> 31 : 0u)))) & (~0u << (x & 31));
                         if (e) pos = 32 * k + __builtin_ctz(e);
                         else
-                            for (k++; k < wpr_; k++) {
-                                const uint32_t b2 = brow[k], t2 = trow[k];
-                                if (!(b2 | t2)) continue;          // most words of a despeckled frame are empty
-                                const uint32_t e2 = t2 | (b2 & ~((b2 << 1) | (brow[k - 1] >> 31)));
+                            for (k = next_word(k + 1); k < wpr_; k = next_word(k + 1)) {   // most words of a despeckled frame are empty
+                                const uint32_t b2 = brow[k];
+                                const uint32_t e2 = trow[k] | (b2 & ~((b2 << 1) | (brow[k - 1] >> 31)));
                                 if (e2) { pos = 32 * k + __builtin_ctz(e2); break; }
                             }
                     }
@@ -291,7 +304,7 @@ class BitScanner {
                 x = pos + 1;
                 if (inside) {                                     // nothing can start before the next right-exit label
                     int nx = -1;
-                    for (int k = x >> 5; k < wpr_; k++) {
+                    for (int k = x >> 5; k < wpr_; k = next_word(k + 1)) {
                         uint32_t e = rrow[k];
                         if (k == (x >> 5)) e &= ~0u << (x & 31);
                         if (e) { nx = 32 * k + __builtin_ctz(e); break; }
@@ -368,6 +381,8 @@ class BitScanner {
 
     const uint32_t *b_;
     int h_, w_, wpr_;
+    const uint64_t *rm_;
+    int gpr_;
     uint32_t *t_ = nullptr, *r_ = nullptr;
     Planes *pl_ = nullptr;
 };
@@ -618,7 +633,7 @@ extern "C" int sv_find_grid_corners_sparse_batch(const uint8_t *records, long re
         static thread_local std::vector<uint32_t> dense;
         dense.resize((size_t)H * (W >> 5));
         if (!sparse_expand(records + (size_t)i * record_stride, H, W, dense.data())) { found[i] = 2; return; }
-        BitScanner sc(dense.data(), H, W);
+        BitScanner sc(dense.data(), H, W, reinterpret_cast<const uint64_t *>(records + (size_t)i * record_stride + 8));
         found[i] = grid_corners_from(sc, H, W, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
     });
     return SV_OK;

@@ -38,6 +38,34 @@ for it in range(60):                                                      # K1
     if not (got == o.preprocess_for_grid_detection(img)).all():
         print("K1 MISMATCH", H, W, kind); sys.exit(1)
     n1 += 1
+n1b = 0
+for it in range(40):                                                      # K1's other forms: bit image, in-place bit despeckle, matrix pipe, fused launch
+    H, W = int(rs.randint(16, 300)), 16 * int(rs.randint(1, 30))
+    n = int(rs.randint(1, 4))
+    img = rs.randint(0, 256, (n, H, W, 3))
+    if it % 2:
+        img = (img * rs.uniform(0.02, 0.3) + rs.randint(0, 180)).astype(np.int64)     # low contrast: many means near the decision boundary
+    d = torch.from_numpy(np.clip(img, 0, 255).astype(np.uint8)).cuda()
+    ref = ctx.preprocess(d)
+    want = np.stack([o.preprocess_for_grid_detection(f) for f in d.cpu().numpy()])
+    if not (ref.cpu().numpy() == want).all() or not torch.equal(ctx.preprocess_mm(d), ref):
+        print("K1 matrix-pipe MISMATCH", n, H, W); sys.exit(1)
+    if W % 32 == 0:
+        bits = ctx.preprocess_bits(d)
+        if not np.array_equal(bits.cpu().numpy().view(np.uint32), np.packbits(want > 0, axis=2, bitorder="little").view(np.uint32).reshape(n, H, W // 32)):
+            print("K1 bit image MISMATCH", n, H, W); sys.exit(1)
+        packed = torch.empty_like(bits)
+        ctx.despeckle(ref, out=torch.empty_like(ref), packed=packed)
+        if not torch.equal(ctx.despeckle_bits(bits), packed):
+            print("despeckle bits MISMATCH", n, H, W); sys.exit(1)
+    side = 0.8 * min(H, W)
+    corners = np.stack([np.array([[W / 2 - side / 2, H / 2 - side / 2], [W / 2 + side / 2, H / 2 - side / 2], [W / 2 + side / 2, H / 2 + side / 2],
+                                  [W / 2 - side / 2, H / 2 + side / 2]]) + rs.uniform(-0.1, 0.1, (4, 2)) * side for _ in range(n)]).astype(np.float32)
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners).reshape(n, 9))
+    b2, c2 = ctx.preprocess_and_warp_cells(d, minv)
+    if not torch.equal(b2, ref) or not torch.equal(c2, ctx.warp_cells(d, minv)):
+        print("fused K1+K2 MISMATCH", n, H, W); sys.exit(1)
+    n1b += 1
 for it in range(60):                                                      # K2
     H, W = int(rs.randint(60, 500)), int(rs.randint(60, 700))
     img = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
@@ -78,4 +106,4 @@ for it in range(120):                                                     # JPEG
     if not (o.imdecode(data) == want).all():
         print("JPEG ORACLE MISMATCH", H, W, kw); sys.exit(1)
     n3 += 1
-print(f"fuzz ok: K1 {n1} shapes, K2 {n2} quads, JPEG {n3} files (seed {sys.argv[1] if len(sys.argv) > 1 else 0})")
+print(f"fuzz ok: K1 {n1} shapes + {n1b} in its other forms (bits, matrix pipe, fused launch), K2 {n2} quads, JPEG {n3} files (seed {sys.argv[1] if len(sys.argv) > 1 else 0})")

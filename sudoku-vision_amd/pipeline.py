@@ -289,7 +289,7 @@ class PipelineResult:
 
 
 def check_constraints(grid):
-    """The messages of pipeline/run.py:69-111 for a 9x9 grid: one entry per repeated value in a row, a column or a box
+    """The messages of pipeline/run.py:205-241 for a 9x9 grid: one entry per repeated value in a row, a column or a box
     (0 = empty is ignored); a value seen three times in a unit yields two entries, each naming the previous occurrence."""
     out = []
     units = [("row", r, [(r, c) for c in range(9)]) for r in range(9)]
@@ -314,7 +314,7 @@ def check_constraints(grid):
 
 
 def run_pipeline(image_path, state_dict=None, ctx=None, debug=False, low_confidence=0.7):
-    """run_pipeline(image_path) of pipeline/run.py:205-334 on the MI355X path: JPEG -> frame in HBM (imgcodecs) -> K1 -> host
+    """run_pipeline(image_path) of pipeline/run.py:244-355 on the MI355X path: JPEG -> frame in HBM (imgcodecs) -> K1 -> host
     corner search -> K2 (warped 450x450 grid kept, as the reference keeps it) -> preprocess_cell + DigitCNN (K3) -> constraint
     check -> in-process solver.  Same PipelineResult fields, same error strings, same partial results on failure."""
     from . import imgcodecs

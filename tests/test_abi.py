@@ -117,7 +117,7 @@ def test_winograd_stream_schedule():
 
 
 def test_check_constraints_messages():
-    """The harness's constraint messages (pipeline/run.py:69-111): format and the 'previous occurrence' rule."""
+    """The harness's constraint messages (pipeline/run.py:205-241): format and the 'previous occurrence' rule."""
     from sudoku_vision_amd.pipeline import check_constraints
     g = [[0] * 9 for _ in range(9)]
     assert check_constraints(g) == []

@@ -95,7 +95,7 @@ def test_imdecode_batch(ctx):
 
 
 def test_run_pipeline_counterpart(ctx, golden_dir, tmp_path):
-    """pipeline/run.py:205-334's run_pipeline on the MI355X path: same result fields, same error strings."""
+    """pipeline/run.py:244-355's run_pipeline on the MI355X path: same result fields, same error strings."""
     import sudoku_vision_amd as sva
     from sudoku_vision_amd.pipeline import PipelineResult, recognize_image, run_pipeline, run_solver, check_constraints
     g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))

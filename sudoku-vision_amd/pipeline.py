@@ -258,7 +258,7 @@ def run_solver(grid):
     return (True, [[int(v) for v in row] for row in sol]) if code == 1 else (False, g)
 
 
-# ---- the harness's own entry point (pipeline/run.py:36-66, 205-334), same result fields and error strings ------------------
+# ---- the harness's own entry point (pipeline/run.py:36-70, 205-241, 244-355), same result fields and error strings ------------------
 @dataclass
 class CellPrediction:
     """pipeline/run.py:36-43"""

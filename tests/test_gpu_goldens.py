@@ -408,3 +408,13 @@ def test_fused_threshold_warp_launch(ctx, n, H, W):
     host = frames[0].cpu().numpy()
     assert (binary[0].cpu().numpy() == o.preprocess_for_grid_detection(host)).all()
     assert (cells[0].cpu().numpy() == o.warp_cells(host, corners[0])).all()
+
+
+@pytest.mark.gpu
+def test_bench_latency_script_runs():
+    """bench_latency.py (BASELINE configs[2]) end to end on a short back-to-back feed: one JSON line, every grid found, sub-5-ms frames."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_latency.py"), "--frames", "24", "--fps", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["frames"] == 24 and d["grids_found"] == 24 and d["unit"] == "ms"
+    assert 0 < d["frame_to_digits"]["p50"] < 5.0

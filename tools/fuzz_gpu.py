@@ -82,6 +82,27 @@ for it in range(60):                                                      # K2
     if not (warped == o.warp_perspective(img, corners)).all():
         print("K2 warp MISMATCH", H, W, corners.tolist()); sys.exit(1)
     n2 += 1
+import cnn_oracle  # noqa: E402
+n4 = 0
+for it in range(12):                                                      # K3: weights of very different magnitudes through the f16-pair kernels
+    sd = cnn_oracle.random_state_dict(1000 + it + 100 * (int(sys.argv[1]) if len(sys.argv) > 1 else 0))
+    for k in sd:
+        if k.endswith("weight"):
+            sd[k] = sd[k] * float(10 ** rs.uniform(-1.5, 1.0))
+    ctx.load_state_dict(sd)
+    B = int(rs.randint(1, 700))
+    x = torch.from_numpy(rs.uniform(-1, 1, (B, 1, 28, 28)).astype(np.float32))
+    want = cnn_oracle.forward(sd, x).numpy()
+    got = ctx.cnn_forward(x.cuda()).cpu().numpy()
+    tol = max(1e-4, 2e-5 * float(np.abs(want).max()))
+    if np.abs(got - want).max() > tol:
+        print("K3 MISMATCH", it, B, np.abs(got - want).max(), tol); sys.exit(1)
+    cells = torch.from_numpy(rs.randint(0, 256, (B, 28, 28)).astype(np.uint8))
+    want = cnn_oracle.forward(sd, torch.from_numpy(o.cells_to_input(cells.numpy())[:, None])).numpy()
+    got = ctx.cnn_forward(cells.cuda()).cpu().numpy()
+    if np.abs(got - want).max() > max(1e-4, 2e-5 * float(np.abs(want).max())):
+        print("K3 (cells) MISMATCH", it, B, np.abs(got - want).max()); sys.exit(1)
+    n4 += 1
 for it in range(120):                                                     # JPEG
     H, W = int(rs.randint(1, 200)), int(rs.randint(1, 300))
     gray = it % 7 == 0
@@ -106,4 +127,4 @@ for it in range(120):                                                     # JPEG
     if not (o.imdecode(data) == want).all():
         print("JPEG ORACLE MISMATCH", H, W, kw); sys.exit(1)
     n3 += 1
-print(f"fuzz ok: K1 {n1} shapes + {n1b} in its other forms (bits, matrix pipe, fused launch), K2 {n2} quads, JPEG {n3} files (seed {sys.argv[1] if len(sys.argv) > 1 else 0})")
+print(f"fuzz ok: K1 {n1} shapes + {n1b} in its other forms (bits, matrix pipe, fused launch), K2 {n2} quads, K3 {n4} weight sets, JPEG {n3} files (seed {sys.argv[1] if len(sys.argv) > 1 else 0})")

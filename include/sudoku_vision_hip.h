@@ -270,7 +270,10 @@ int sv_warp_cells_u8(sv_ctx *ctx, const uint8_t *frames /*dev*/, int n, int H, i
 /* ---- K3: DigitCNN forward (ml/model.py) --------------------------------------------------------- */
 
 /* DigitCNN.forward, ml/model.py:34-42 (eval mode): x f32 [B,1,28,28] -> logits f32 [B,10].
- * digits (argmax, pipeline/run.py:142) and conf (softmax[argmax], :141-143) may be NULL. */
+ * digits (argmax, pipeline/run.py:142) and conf (softmax[argmax], :141-143) may be NULL.
+ * Range: the default kernels (csrc/k3_cnn_h2.hip) carry inputs and activations as f16 pairs (f32-grade accuracy, ~1e-6 on the
+ * logits): their magnitudes must stay below 65,504.  The model's inputs are in [-1, 1] and its activations below ~100 with any
+ * trained weights; SV_CONV_ALGO=2 (environment, read once per process) selects the f32-MFMA kernels, which have no such limit. */
 int sv_cnn_forward_f32(sv_ctx *ctx, const float *x /*dev*/, long B, float *logits /*dev, B*10*/,
                        uint8_t *digits /*dev, B, or NULL*/, float *conf /*dev, B, or NULL*/,
                        void *stream);

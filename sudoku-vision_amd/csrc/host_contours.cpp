@@ -240,10 +240,13 @@ class BitScanner {
     {
         Planes &tl = planes();
         const size_t words = (size_t)H * wpr_;
-        if (tl.t.size() != words) {
+        // the planes and the per-row dirty spans are laid out for one (H, words per row): two shapes with the same word count
+        // (480x640 and 640x480) must not share them
+        if (tl.h != H || tl.wpr != wpr_) {
             tl.t.assign(words, 0);
             tl.r.assign(words, 0);
             tl.dirty.assign((size_t)H, {0, 0});
+            tl.h = H; tl.wpr = wpr_;
         } else {
             for (int y = tl.y0; y <= tl.y1; y++) {                 // only the word spans the previous frame's borders touched
                 auto &d = tl.dirty[y];
@@ -321,7 +324,7 @@ class BitScanner {
     std::vector<Contour> contours;  // in discovery order (cv2 reports them reversed)
 
   private:
-    struct Planes { std::vector<uint32_t> t, r; std::vector<std::pair<int, int>> dirty; int y0 = 0, y1 = -1; };
+    struct Planes { std::vector<uint32_t> t, r; std::vector<std::pair<int, int>> dirty; int y0 = 0, y1 = -1; int h = 0, wpr = 0; };
     static Planes &planes() { static thread_local Planes p; return p; }
 
     inline bool set(int x, int y) const { return (unsigned)x < (unsigned)w_ && (unsigned)y < (unsigned)h_ && (b_[(size_t)y * wpr_ + (x >> 5)] >> (x & 31) & 1u); }
@@ -596,15 +599,31 @@ extern "C" int sv_find_grid_corners_bits_batch(const uint32_t *bits, int n, int 
     return SV_OK;
 }
 
-// sparse record (include/sudoku_vision_hip.h, sv_pack_sparse_bits) -> dense bit image; false if the record overflowed
-static bool sparse_expand(const uint8_t *record, int H, int W, uint32_t *bits)
+// sparse record (include/sudoku_vision_hip.h, sv_pack_sparse_bits) -> dense bit image.  The record is validated before anything is
+// written from it (it crosses PCIe and may be stale, torn or built for another shape): 1 = expanded, 0 = the record overflowed its
+// capacity (n_values > cap_values: use the dense image), -1 = malformed (a mask bit beyond the row, more mask bits than values, or
+// a capacity that does not fit `avail` bytes; avail < 0 = unknown, trust cap_values).
+static int sparse_expand(const uint8_t *record, long avail, int H, int W, uint32_t *bits)
 {
     const int wpr = W >> 5, gpr = (wpr + 63) / 64;
+    const size_t head_bytes = 8 + 8 * (size_t)H * gpr;
+    if (avail >= 0 && (size_t)avail < head_bytes) return -1;
     uint32_t head[2];
     memcpy(head, record, 8);
-    if (head[0] > head[1]) return false;
+    if (avail >= 0 && head_bytes + 4 * (size_t)head[1] > (size_t)avail) return -1;
+    if (head[0] > head[1]) return 0;
     const uint64_t *masks = reinterpret_cast<const uint64_t *>(record + 8);
-    const uint32_t *val = reinterpret_cast<const uint32_t *>(record + 8 + 8 * (size_t)H * gpr);
+    const uint32_t *val = reinterpret_cast<const uint32_t *>(record + head_bytes);
+    const int tail = wpr & 63;                                   // valid bits of a row's last mask word (0 = all 64)
+    const uint64_t tail_bad = tail ? ~0ull << tail : 0ull;
+    size_t total = 0;
+    for (int y = 0; y < H; y++)
+        for (int g = 0; g < gpr; g++) {
+            const uint64_t m = masks[(size_t)y * gpr + g];
+            if (g == gpr - 1 && (m & tail_bad)) return -1;
+            total += (size_t)__builtin_popcountll(m);
+        }
+    if (total != head[0]) return -1;
     memset(bits, 0, (size_t)H * wpr * 4);
     for (int y = 0; y < H; y++)
         for (int g = 0; g < gpr; g++) {
@@ -612,27 +631,31 @@ static bool sparse_expand(const uint8_t *record, int H, int W, uint32_t *bits)
             uint32_t *row = bits + (size_t)y * wpr + 64 * g;
             while (m) { row[__builtin_ctzll(m)] = *val++; m &= m - 1; }
         }
-    return true;
+    return 1;
 }
 
 extern "C" int sv_sparse_bits_expand(const uint8_t *record, int H, int W, uint32_t *bits)
 {
     if (!record || !bits || H <= 0 || W <= 0 || (W & 31) || ((uintptr_t)record & 7)) return sv_fail(SV_ERR_BAD_ARG, "sv_sparse_bits_expand: bad argument");
-    if (!sparse_expand(record, H, W, bits)) return sv_fail(SV_ERR_BUFFER, "sv_sparse_bits_expand: the record overflowed its capacity");
+    const int r = sparse_expand(record, -1, H, W, bits);
+    if (r == 0) return sv_fail(SV_ERR_BUFFER, "sv_sparse_bits_expand: the record overflowed its capacity");
+    if (r < 0) return sv_fail(SV_ERR_BAD_ARG, "sv_sparse_bits_expand: malformed record (mask bits outside the row, or mask bits != n_values)");
     return SV_OK;
 }
 
 extern "C" int sv_find_grid_corners_sparse_batch(const uint8_t *records, long record_stride, int n, int H, int W, double min_area_ratio, double epsilon_ratio,
                                                  int *corners, uint8_t *found, int threads)
 {
-    if (!records || !corners || !found || n <= 0 || H <= 0 || W <= 0 || (W & 31) || (record_stride & 7) || ((uintptr_t)records & 7))
+    if (!records || !corners || !found || n <= 0 || H <= 0 || W <= 0 || (W & 31) || (record_stride & 7) || ((uintptr_t)records & 7) ||
+        record_stride < 8 + 8 * (long)H * ((((long)W >> 5) + 63) / 64))
         return sv_fail(SV_ERR_BAD_ARG, "sv_find_grid_corners_sparse_batch: bad argument");
     if (threads < 1) threads = 1;
     if (threads > n) threads = n;
     WorkerPool::instance().parallel_for(n, threads, [&](int i) {
         static thread_local std::vector<uint32_t> dense;
         dense.resize((size_t)H * (W >> 5));
-        if (!sparse_expand(records + (size_t)i * record_stride, H, W, dense.data())) { found[i] = 2; return; }
+        // overflowed or malformed (stale / torn / foreign) record: the caller searches the dense image of that frame instead
+        if (sparse_expand(records + (size_t)i * record_stride, record_stride, H, W, dense.data()) != 1) { found[i] = 2; return; }
         BitScanner sc(dense.data(), H, W, reinterpret_cast<const uint64_t *>(records + (size_t)i * record_stride + 8));
         found[i] = grid_corners_from(sc, H, W, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
     });

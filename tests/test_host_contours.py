@@ -254,3 +254,59 @@ def test_pool_affinity(host):
     finally:
         host.set_pool_affinity(allowed)
     assert host._native.lib().sv_host_pool_set_affinity(None, 3) != 0          # SV_ERR_BAD_ARG
+
+
+def test_bit_scanner_shapes_with_equal_word_count(host):
+    """480x640 and 640x480 have the same number of bit-plane words (9600); the per-thread label planes and
+    per-row dirty spans of the bit scanner must be rebuilt when H or words-per-row change, not only when their product does.
+    One thread, landscape -> portrait -> landscape, every result against the byte scanner."""
+    def frame(seed, h, w):
+        b = _blobs(seed, h, w, thr=0.6)
+        b[h // 6:h - h // 6, w // 6:w // 6 + 4] = 255
+        b[h // 6:h - h // 6, w - w // 6 - 4:w - w // 6] = 255
+        b[h // 6:h // 6 + 4, w // 6:w - w // 6] = 255
+        b[h - h // 6 - 4:h - h // 6, w // 6:w - w // 6] = 255
+        return b
+    for rep, (h, w) in enumerate([(480, 640), (640, 480), (480, 640), (96, 3200), (3200, 96), (640, 480)]):
+        img = frame(rep, h, w)
+        bits = np.packbits(img != 0, axis=1, bitorder="little").view(np.uint32)
+        cb, fb = host.find_grid_corners_bits_batch(bits[None], h, w, 0.05, 0.02, 1)
+        cu, fu = host.find_grid_corners_batch(img[None], 0.05, 0.02, 1)
+        assert np.array_equal(fb.astype(bool), fu.astype(bool)) and np.array_equal(cb, cu), (h, w)
+
+
+def test_sparse_record_validation(host):
+    """a stale, torn or foreign sparse record must be rejected, never expanded past the row or the record."""
+    H, W = 40, 2752                                               # wpr = 86: the second mask word of a row has 22 valid bits
+    rng = np.random.RandomState(5)
+    b = rng.rand(H, W) < 0.05
+    bits = np.packbits(b, axis=1, bitorder="little").view(np.uint32)
+    good = _pack_sparse_np(host, bits, H * (W // 32))
+    assert np.array_equal(host.sparse_bits_expand(good, H, W), bits)
+    gpr = 2
+    # (1) a mask bit beyond the last word of the row
+    bad = good.copy()
+    m = bad[8:8 + 8 * H * gpr].view(np.uint64)
+    m[1] |= np.uint64(1) << np.uint64(40)
+    with pytest.raises(Exception):
+        host.sparse_bits_expand(bad, H, W)
+    # (2) more mask bits than n_values says (a torn record: masks of one frame, header of another)
+    bad = good.copy()
+    bad[:4] = np.array([3], np.uint32).view(np.uint8)
+    with pytest.raises(Exception):
+        host.sparse_bits_expand(bad, H, W)
+    # (3) a capacity that does not fit the stride
+    bad = good.copy()
+    bad[:8] = np.array([10, 1 << 30], np.uint32).view(np.uint8)
+    _, f = host.find_grid_corners_sparse_batch(bad[None], H, W, 0.01, 0.02, 1)
+    assert f[0] == 2
+    # the batch search reports all three as "search the dense image" and never crashes; the good one is searched
+    recs = np.stack([good, bad])
+    _, f = host.find_grid_corners_sparse_batch(recs, H, W, 0.01, 0.02, 1)
+    assert f[0] in (0, 1) and f[1] == 2
+    # (4) a stride smaller than the header + masks
+    import ctypes as C
+    lib = host._native.lib()
+    out = np.zeros(8, np.int32); fo = np.zeros(1, np.uint8)
+    assert lib.sv_find_grid_corners_sparse_batch(good.ctypes.data_as(C.c_void_p), C.c_long(64), 1, H, W, C.c_double(0.01), C.c_double(0.02),
+                                                 out.ctypes.data_as(C.c_void_p), fo.ctypes.data_as(C.c_void_p), 1) == -1

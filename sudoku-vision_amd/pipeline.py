@@ -143,13 +143,14 @@ class FramePipeline:
                 f"{self.host_threads} host threads -> K2 -> K3, {self.chunk}-frame chunks, {self.depth} in flight"
                 + (f", host threads on the GPU's NUMA node ({len(self.cpus)} CPUs)" if self.cpus else ""))
 
-    def run(self, frames, out=None, repeat=1):
+    def run(self, frames, out=None, repeat=1, total=None):
         """frames u8 [n,H,W,3] on the context's device -> dict(digits u8[n,81], logits f32[n,81,10], conf f32[n,81],
         corners int32[n,4,2] (host), found bool[n] (host)).  repeat > 1 streams the pool that many times through the
-        pipeline without draining it in between (steady-state throughput measurement); needs chunk | n."""
+        pipeline without draining it in between (steady-state throughput measurement); total = k streams exactly k frames,
+        cycling the pool (the k-th frame is pool frame k mod n: BASELINE configs[3]'s shard of 100,000 frames); both need chunk | n."""
         n = frames.shape[0]
-        if repeat > 1 and n % self.chunk:
-            raise ValueError("repeat needs the chunk size to divide the number of frames")
+        if (repeat > 1 or total is not None) and n % self.chunk:
+            raise ValueError("repeat / total need the chunk size to divide the number of frames")
         dev = self.ctx.device
         if out is None:
             out = {"logits": torch.empty((n, 81, 10), dtype=torch.float32, device=dev),
@@ -166,7 +167,10 @@ class FramePipeline:
                        and self.H >= 16 and self.W >= 16)
         if not bits_direct and self.dev_bin is None:
             self.dev_bin = [torch.empty((self.chunk, self.H, self.W), dtype=torch.uint8, device=dev) for _ in range(self.depth)]
-        starts = [s0 for _ in range(repeat) for s0 in range(0, n, self.chunk)]
+        if total is None:
+            starts = [(s0, min(self.chunk, n - s0)) for _ in range(repeat) for s0 in range(0, n, self.chunk)]
+        else:
+            starts = [((k * self.chunk) % n, min(self.chunk, total - k * self.chunk)) for k in range((total + self.chunk - 1) // self.chunk)]
         pending = []                                  # (future, slot, start, m)
         free_ev = [None] * self.depth                 # classification done with slot's buffers
 
@@ -184,9 +188,8 @@ class FramePipeline:
                 ev.record(self.s_cls)
                 free_ev[slot] = ev
 
-        for i, s in enumerate(starts):
+        for i, (s, m) in enumerate(starts):
             slot = i % self.depth
-            m = min(self.chunk, n - s)
             if free_ev[slot] is not None:
                 free_ev[slot].synchronize()
             with torch.cuda.stream(self.s_pre):

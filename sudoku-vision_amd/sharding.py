@@ -86,6 +86,15 @@ def max_over_ranks(value: float) -> float:
     return float(t.item())
 
 
+def gather_objects(obj):
+    """-> [rank 0's obj, rank 1's, ...] on every rank (a list of one without a group): small host-side records, e.g. which GPU a rank sits on."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def gather_digits(local_digits: torch.Tensor, n_total: int, rank: int, world: int):
     """Reassembles per-rank digit tensors [n_local,81] into frame order [n_total,81] on every rank (host-sized data; device
     tensors are gathered through the host, the group being gloo)."""

@@ -191,30 +191,51 @@ def _bench(args, env=None, timeout=600):
 
 def test_bench_starts_its_own_ranks(ctx):
     """`python bench.py --gpus 2` with no outer launcher: two ranks (both on cuda:0 under SV_BENCH_REHEARSE=1), n_gpus = 2 in
-    the line, weak scaling counts both ranks' frames; configs[3]'s round-robin workload at a small total."""
-    res = _bench(["--gpus", "2", "--frames", "32", "--steps", "3", "--warmup", "1", "--e2e-passes", "0", "--no-cpu-baseline"],
+    the line, weak scaling counts both ranks' frames, `ranks` names each rank's GPU; configs[3]'s round-robin workload at a small total."""
+    res = _bench(["--gpus", "2", "--frames", "32", "--steps", "3", "--warmup", "1", "--no-e2e", "--no-cpu-baseline"],
                  env={"SV_BENCH_REHEARSE": "1"})
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak" and res["value_kind"] == "device_only"
     assert res["config"]["frames_per_step"] == 64
     assert abs(res["value"] - 64 * 3 / (res["ms_per_step"] * 3e-3)) <= 1e-6 * res["value"]
     assert 0 < res["roofline"]["frac"] <= 1.0
+    assert [r["rank"] for r in res["ranks"]] == [0, 1] and len({r["pid"] for r in res["ranks"]}) == 2
+    assert all(r["pci_bus_id"] and r["device"] for r in res["ranks"])
     res3 = _bench(["--gpus", "2", "--workload", "configs3", "--total-frames", "301", "--frames", "32", "--steps", "2", "--warmup", "1"],
                   env={"SV_BENCH_REHEARSE": "1"})
     assert res3["n_gpus"] == 2 and res3["scaling"] == "strong" and res3["config"]["frames_per_step"] == 301
     assert res3["config"]["frames_per_gpu"] == 151                        # rank 0 owns frames 0, 2, ..., 300
     assert res3["kernels"]["k_preprocess"]["launches"] == 2 * 5           # 151 = 4 x 32 + 23: five launches per step
+    assert res3["value_kind"] == "end_to_end" and res3["end_to_end_with_host_corner_search"]["grids_found"] == 32
 
 
 def test_bench_single_gpu_line_is_honest(ctx):
-    """--gpus 1 line: roofline.frac <= 1 and reproducible from its own fields, device-only and end-to-end values labelled."""
-    res = _bench(["--frames", "64", "--steps", "3", "--warmup", "1", "--e2e-passes", "2", "--no-cpu-baseline"])
+    """--gpus 1 line: value = the end-to-end figure BASELINE's metric names, value_device_only beside it; roofline.frac <= 1 and
+    reproducible from its own fields; the traffic constant says where it comes from."""
+    res = _bench(["--frames", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
     rf = res["roofline"]
-    assert res["n_gpus"] == 1 and res["value_kind"] == "device_only"
-    assert res["value_end_to_end"] == res["end_to_end_with_host_corner_search"]["value"] < res["value"]
+    e2e = res["end_to_end_with_host_corner_search"]
+    assert res["n_gpus"] == 1 and res["value_kind"] == "end_to_end" and res["metric"].startswith("end-to-end")
+    assert res["value"] == res["value_end_to_end"] == e2e["value"] < res["value_device_only"]
+    assert abs(res["value"] - 64 * 3 / (res["ms_per_step"] * 3e-3)) <= 1e-6 * res["value"]
+    assert sorted(e2e["regions"])[1] == e2e["value"] and e2e["grids_found"] == e2e["of"] == 64
     assert 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert len(res["ranks"]) == 1 and res["ranks"][0]["rank"] == 0 and res["ranks"][0]["pci_bus_id"]
     if rf["kernel"] == "k_conv_features":
         k = res["kernels"]["k_conv_features"]
         assert abs(rf["achieved"] * 1e12 - rf["issued_flop_per_cell"] * 81 * 64 / (k["avg_ms"] * 1e-3)) <= 1e-6 * rf["achieved"] * 1e12
+
+
+def test_bench_configs3_full_size(ctx):
+    """BASELINE configs[3] at its stated size on one GPU: 100,000 frames through the 256-frame pool in one step.  Every kernel is
+    launched ceil(100000/256) times, the step covers 100,000 frames, and the per-GPU device-only rate is that of configs[1]."""
+    res = _bench(["--workload", "configs3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], timeout=900)
+    assert res["scaling"] == "strong" and res["config"]["frames_per_step"] == 100000 and res["config"]["frames_per_gpu"] == 100000
+    launches = -(-100000 // 256)
+    for k in ("k_preprocess", "k_warp_cells", "k_conv_features", "k_fc_head"):
+        assert res["kernels"][k]["launches"] == launches, k
+    assert res["value_kind"] == "end_to_end" and res["end_to_end_with_host_corner_search"]["grids_found"] == 256
+    ref = _bench(["--steps", "40", "--warmup", "10", "--no-e2e", "--no-cpu-baseline"])
+    assert abs(res["per_gpu_value_device_only"] / ref["value"] - 1) <= 0.05, (res["per_gpu_value_device_only"], ref["value"])
 
 
 def test_degenerate_quad_does_not_abort_the_batch(ctx, golden_dir, monkeypatch):

@@ -134,7 +134,7 @@ def test_bench_scripts_touch_the_oracle_only_in_cpu_baseline():
             if isinstance(node, ast.FunctionDef):
                 src = ast.get_source_segment(open(os.path.join(ROOT, name)).read(), node)
                 if "oracle" in src:
-                    assert node.name == "cpu_baseline", f"{name}:{node.name} mentions the oracle"
+                    assert node.name in ("cpu_baseline", "cpu_baseline_test_image"), f"{name}:{node.name} mentions the oracle"
         top = [n for n in tree.body if not isinstance(n, (ast.FunctionDef, ast.Expr))]
         for n in top:
             assert "oracle" not in ast.get_source_segment(open(os.path.join(ROOT, name)).read(), n)

@@ -9,6 +9,7 @@
 // Built for throughput: the raster scan skips runs 8 bytes at a time, small contours are rejected by
 // bounding box before any area/approximation work, and a batch entry point spreads frames over threads.
 #include <algorithm>
+#include <immintrin.h>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -232,149 +233,217 @@ class BorderScanner {
 // start at such a run start iff the last label passed on the row was a right-exit (or there was none); once a positive label has been
 // passed nothing can start before the next right-exit, so the scan jumps there -- the lines and digits inside a followed grid
 // border cost nothing.  Same borders, same points, same order as BorderScanner (tests/test_host_contours.py compares them).
-class BitScanner {
-  public:
-    // rowmask (optional): per row and group of 64 words, bit k = word 64g + k of the row is non-zero (the sparse record's masks): the raster
-    // scan then steps from one non-zero word to the next instead of testing every word, and skips empty rows outright
-    BitScanner(const uint32_t *bits, int H, int W, const uint64_t *rowmask = nullptr) : b_(bits), h_(H), w_(W), wpr_(W >> 5), rm_(rowmask), gpr_(((W >> 5) + 63) / 64)
+//
+// Layout (round 3): image and label planes live in per-thread buffers with one zero word left and right of every row and one zero
+// row above and below, so neither the raster scan nor the border following ever tests a coordinate against the frame.  Following a
+// border is table-driven: the 3x3 neighbourhood of the current pixel is three unaligned loads, and (neighbourhood, direction we came
+// from) -> (next direction, "the right neighbour was examined and is clear") is one look-up in a 4-KB table built from the very loop
+// BorderScanner::follow runs.  Per row, 64-bit masks say which words hold set pixels (from the sparse record, or built while the
+// dense image is copied in) and which hold right-exit labels, so both the run-start search and the jump across a followed interior
+// step from one interesting word to the next.
+struct BitScratch {
+    std::vector<uint32_t> img;                  // [(H + 2) * (wpr + 2)] (+ slack for the vector expansion's full-group stores)
+    std::vector<uint32_t> lab;                  // label planes, interleaved: lab[2i] = T word i, lab[2i + 1] = R word i (one cache line per mark)
+    std::vector<uint64_t> bmask, rmask;         // [H * gpr]: words of the row with set pixels / with right-exit labels
+    struct Touched { uint32_t word, group; };   // label words (and their rmask group) written by the current frame's borders
+    std::vector<Touched> touched;
+    std::vector<Pt> points;
+    std::vector<Contour> contours;
+    int h = 0, wpr = 0, gpr = 0, stride = 0;
+    bool dirty_img = false;
+
+    static BitScratch &get() { static thread_local BitScratch s; return s; }
+
+    // ready for a frame of this shape: image all zero, labels all zero, no points
+    // Invariant between frames: img is non-zero exactly in the words bmask names.  keep_img: the caller replaces the old frame by the new
+    // one chunk by chunk itself (the vector expansion, which needs the old masks for that); otherwise the image is zeroed here
+    void begin(int H, int W, bool keep_img = false)
     {
-        Planes &tl = planes();
-        const size_t words = (size_t)H * wpr_;
-        // the planes and the per-row dirty spans are laid out for one (H, words per row): two shapes with the same word count
-        // (480x640 and 640x480) must not share them
-        if (tl.h != H || tl.wpr != wpr_) {
-            tl.t.assign(words, 0);
-            tl.r.assign(words, 0);
-            tl.dirty.assign((size_t)H, {0, 0});
-            tl.h = H; tl.wpr = wpr_;
-        } else {
-            for (int y = tl.y0; y <= tl.y1; y++) {                 // only the word spans the previous frame's borders touched
-                auto &d = tl.dirty[y];
-                if (d.second > d.first) {
-                    memset(tl.t.data() + (size_t)y * wpr_ + d.first, 0, (size_t)(d.second - d.first) * 4);
-                    memset(tl.r.data() + (size_t)y * wpr_ + d.first, 0, (size_t)(d.second - d.first) * 4);
-                }
-                d = {0, 0};
+        const int w = W >> 5;
+        if (h != H || wpr != w) {               // (H, words per row) -- not their product: 480x640 and 640x480 share a word count
+            h = H; wpr = w; gpr = (w + 63) / 64; stride = w + 2;
+            img.assign((size_t)(H + 2) * stride + 64, 0u);
+            lab.assign((size_t)(H + 2) * stride * 2, 0u);
+            bmask.assign((size_t)H * gpr, 0ull);
+            rmask.assign((size_t)H * gpr, 0ull);
+            touched.clear();
+            dirty_img = false;
+        }
+        if (dirty_img && !keep_img) memset(img.data(), 0, img.size() * 4);
+        for (const Touched &x : touched) { lab[2 * (size_t)x.word] = 0; lab[2 * (size_t)x.word + 1] = 0; rmask[x.group] = 0; }
+        touched.clear();
+        points.clear();
+        contours.clear();
+        dirty_img = true;
+    }
+    uint32_t *row(int y) { return img.data() + (size_t)(y + 1) * stride + 1; }   // word 0 of image row y
+
+    // dense bit image (H rows of wpr words) -> padded image + row masks
+    void load_dense(const uint32_t *bits)
+    {
+        for (int y = 0; y < h; y++) {
+            const uint32_t *s = bits + (size_t)y * wpr;
+            uint32_t *d = row(y);
+            memcpy(d, s, (size_t)wpr * 4);
+            for (int g = 0; g < gpr; g++) {
+                uint64_t m = 0;
+                const int k1 = std::min(wpr, 64 * g + 64);
+                for (int k = 64 * g; k < k1; k++) m |= (uint64_t)(s[k] != 0) << (k & 63);
+                bmask[(size_t)y * gpr + g] = m;
             }
         }
-        tl.y0 = H; tl.y1 = -1;
-        t_ = tl.t.data(); r_ = tl.r.data(); pl_ = &tl;
     }
+};
+
+// (3x3 neighbourhood, direction of the previous border pixel) -> next direction | right-neighbour-examined << 3; and the neighbourhood
+// as an 8-bit mask over the directions of kDx/kDy.  code9 = row above | row << 3 | row below << 6, each 3 bits (x-1, x, x+1).
+struct FollowTable {
+    uint8_t next[512][8];
+    uint8_t nb8[512];
+    FollowTable()
+    {
+        for (int c = 0; c < 512; c++) {
+            const int up = c & 7, mid = (c >> 3) & 7, dn = c >> 6;
+            const int m = ((mid >> 2) & 1) | ((up >> 2) & 1) << 1 | ((up >> 1) & 1) << 2 | (up & 1) << 3 | (mid & 1) << 4 | (dn & 1) << 5 | ((dn >> 1) & 1) << 6 |
+                          ((dn >> 2) & 1) << 7;
+            nb8[c] = (uint8_t)m;
+            for (int s_from = 0; s_from < 8; s_from++) {
+                int s = s_from;
+                while (s < 15) {                                   // BorderScanner::follow's search, counter-clockwise from the previous pixel
+                    ++s;
+                    if ((m >> (s & 7)) & 1) break;
+                }
+                s &= 7;
+                const bool right = (unsigned)(s - 1) < (unsigned)s_from;
+                next[c][s_from] = (uint8_t)(s | (right ? 8 : 0));
+            }
+        }
+    }
+};
+const FollowTable kFollow;
+
+class BitScanner {
+  public:
+    // the scratch must hold the frame already (BitScratch::begin + load_dense, or sparse_expand)
+    BitScanner(BitScratch &sc, int H, int W) : sc_(sc), h_(H), wpr_(W >> 5), gpr_(sc.gpr), stride_(sc.stride), img_(sc.img.data()), lab_(sc.lab.data()),
+                                               points(sc.points), contours(sc.contours) {}
 
     void run()
     {
         for (int y = 0; y < h_; y++) {
-            const uint32_t *brow = b_ + (size_t)y * wpr_;
-            const uint32_t *trow = t_ + (size_t)y * wpr_, *rrow = r_ + (size_t)y * wpr_;
-            const uint64_t *rm = rm_ ? rm_ + (size_t)y * gpr_ : nullptr;
-            // first word >= k that has a set pixel (labels only ever sit on set pixels), or wpr_
+            const uint64_t *bm = sc_.bmask.data() + (size_t)y * gpr_;
+            // first word >= k with a set pixel (labels only ever sit on set pixels), or wpr_
             auto next_word = [&](int k) -> int {
-                if (!rm) { while (k < wpr_ && !brow[k]) k++; return k; }
                 while (k < wpr_) {
-                    const uint64_t m = rm[k >> 6] >> (k & 63);
+                    const uint64_t m = bm[k >> 6] >> (k & 63);
                     if (m) return k + __builtin_ctzll(m);
                     k = (k | 63) + 1;
                 }
                 return wpr_;
             };
-            if (next_word(0) >= wpr_) continue;                   // empty row
-            bool inside = false;                                  // the last label passed on this row is positive
-            int x = 0;
+            int k = next_word(0);
+            if (k >= wpr_) continue;                               // empty row
+            const size_t base = (size_t)(y + 1) * stride_ + 1;
+            const uint32_t *brow = img_ + base, *lrow = lab_ + 2 * base;      // lrow[2k] = T word k, lrow[2k + 1] = R word k
+            int x = 32 * k;
             for (;;) {
-                // next pixel >= x that is labelled or starts a run
+                // next pixel >= x that is labelled or starts a run (brow[-1] is the zero pad word)
                 int pos = -1;
-                {
-                    int k = x >> 5;
-                    if (k < wpr_) {                                // first word: only the bits from x on
-                        const uint32_t bw = brow[k];
-                        const uint32_t e = (trow[k] | (bw & ~((bw << 1) | (k ? brow[k - 1] >> 31 : 0u)))) & (~0u << (x & 31));
-                        if (e) pos = 32 * k + __builtin_ctz(e);
-                        else
-                            for (k = next_word(k + 1); k < wpr_; k = next_word(k + 1)) {   // most words of a despeckled frame are empty
-                                const uint32_t b2 = brow[k];
-                                const uint32_t e2 = trow[k] | (b2 & ~((b2 << 1) | (brow[k - 1] >> 31)));
-                                if (e2) { pos = 32 * k + __builtin_ctz(e2); break; }
-                            }
-                    }
+                k = x >> 5;
+                if (k < wpr_) {
+                    const uint32_t bw = brow[k];
+                    const uint32_t e = (lrow[2 * k] | (bw & ~((bw << 1) | (brow[k - 1] >> 31)))) & (~0u << (x & 31));
+                    if (e) pos = 32 * k + __builtin_ctz(e);
+                    else
+                        for (k = next_word(k + 1); k < wpr_; k = next_word(k + 1)) {
+                            const uint32_t b2 = brow[k];
+                            const uint32_t e2 = lrow[2 * k] | (b2 & ~((b2 << 1) | (brow[k - 1] >> 31)));
+                            if (e2) { pos = 32 * k + __builtin_ctz(e2); break; }
+                        }
                 }
                 if (pos < 0) break;
                 const uint32_t m = 1u << (pos & 31);
-                if (!(trow[pos >> 5] & m)) {
-                    if (!inside) follow(pos, y);                  // labels (pos, y) among others
-                    else { x = pos + 1; continue; }               // (not reached: `inside` jumps below)
-                }
-                inside = !(rrow[pos >> 5] & m);
+                if (!(lrow[2 * (pos >> 5)] & m)) follow(pos, y);         // an unlabelled run start with no positive label pending: a new outer border
                 x = pos + 1;
-                if (inside) {                                     // nothing can start before the next right-exit label
+                if (!(lrow[2 * (pos >> 5) + 1] & m)) {               // positive label: nothing can start before the next right-exit label of the row
+                    const uint64_t *rm = sc_.rmask.data() + (size_t)y * gpr_;
                     int nx = -1;
-                    for (int k = x >> 5; k < wpr_; k = next_word(k + 1)) {
-                        uint32_t e = rrow[k];
-                        if (k == (x >> 5)) e &= ~0u << (x & 31);
-                        if (e) { nx = 32 * k + __builtin_ctz(e); break; }
+                    for (int kk = x >> 5; kk < wpr_;) {
+                        uint64_t mm = rm[kk >> 6] >> (kk & 63);
+                        if (!mm) { kk = (kk | 63) + 1; continue; }
+                        kk += __builtin_ctzll(mm);
+                        uint32_t e = lrow[2 * kk + 1];
+                        if (kk == (x >> 5)) e &= ~0u << (x & 31);
+                        if (e) { nx = 32 * kk + __builtin_ctz(e); break; }
+                        kk++;
                     }
                     if (nx < 0) break;
-                    inside = false;
                     x = nx + 1;
                 }
             }
         }
     }
 
-    std::vector<Pt> points;
-    std::vector<Contour> contours;  // in discovery order (cv2 reports them reversed)
-
   private:
-    struct Planes { std::vector<uint32_t> t, r; std::vector<std::pair<int, int>> dirty; int y0 = 0, y1 = -1; int h = 0, wpr = 0; };
-    static Planes &planes() { static thread_local Planes p; return p; }
-
-    inline bool set(int x, int y) const { return (unsigned)x < (unsigned)w_ && (unsigned)y < (unsigned)h_ && (b_[(size_t)y * wpr_ + (x >> 5)] >> (x & 31) & 1u); }
-    inline void touch(int x, int y)
+    // 3x3 neighbourhood of pixel x in the padded row whose bytes start at rp (rows above / below are rb bytes away)
+    static inline unsigned code9(const uint8_t *rp, ptrdiff_t rb, int x)
     {
-        auto &d = pl_->dirty[y];
-        const int k = x >> 5;
-        if (d.second == d.first) d = {k, k + 1};
-        else { if (k < d.first) d.first = k; if (k + 1 > d.second) d.second = k + 1; }
-        if (y < pl_->y0) pl_->y0 = y;
-        if (y > pl_->y1) pl_->y1 = y;
+        const unsigned bit = (unsigned)x + 31u;                    // bit index of pixel x-1 in the padded row
+        const uint8_t *p = rp + (bit >> 3);
+        const unsigned sh = bit & 7;
+        uint32_t u, m, d;
+        memcpy(&u, p - rb, 4);
+        memcpy(&m, p, 4);
+        memcpy(&d, p + rb, 4);
+        return ((u >> sh) & 7) | (((m >> sh) & 7) << 3) | (((d >> sh) & 7) << 6);
     }
-    inline void mark_right(int x, int y) { touch(x, y); const size_t i = (size_t)y * wpr_ + (x >> 5); t_[i] |= 1u << (x & 31); r_[i] |= 1u << (x & 31); }
-    inline void mark_plain(int x, int y) { const size_t i = (size_t)y * wpr_ + (x >> 5); if (!(t_[i] >> (x & 31) & 1u)) { touch(x, y); t_[i] |= 1u << (x & 31); } }
+    // labels pixel x of the row whose label words start at lr (padded word 0) and whose rmask groups start at rmg
+    inline void mark(uint32_t *lr, uint64_t *rmg, int x, bool right)
+    {
+        const int k = (x >> 5) + 1;
+        const uint32_t m = 1u << (x & 31);
+        uint32_t *w = lr + 2 * k;
+        if (!w[0]) sc_.touched.push_back({(uint32_t)((w - lab_) >> 1), (uint32_t)(rmg - sc_.rmask.data() + (x >> 11))});
+        w[0] |= m;
+        if (right) { w[1] |= m; rmg[x >> 11] |= 1ull << ((x >> 5) & 63); }
+    }
 
-    // BorderScanner::follow on the bit planes (x, y are image coordinates here; the byte scanner's are the same minus its padding)
+    // BorderScanner::follow on the bit planes (x, y are image coordinates; the byte scanner's are the same minus its padding)
     void follow(int sx, int sy)
     {
         Contour c{points.size(), 0, sx, sy, sx, sy};
+        const ptrdiff_t rb = (ptrdiff_t)stride_ * 4;
+        const uint8_t *rp = reinterpret_cast<const uint8_t *>(img_ + (size_t)(sy + 1) * stride_);
+        uint32_t *lr = lab_ + 2 * (size_t)(sy + 1) * stride_;
+        uint64_t *rmg = sc_.rmask.data() + (size_t)sy * gpr_;
+        const unsigned nb0 = kFollow.nb8[code9(rp, rb, sx)];
         int s = 4;
-        const int s_stop = 4;
-        int x2, y2;
         do {
             s = (s - 1) & 7;
-            x2 = sx + kDx[s]; y2 = sy + kDy[s];
-        } while (!set(x2, y2) && s != s_stop);
-        if (s == s_stop) {  // isolated pixel
-            mark_right(sx, sy);
+        } while (!((nb0 >> s) & 1) && s != 4);
+        if (s == 4) {  // isolated pixel (the start pixel's left neighbour is clear: it starts a run)
+            mark(lr, rmg, sx, true);
             points.push_back({sx, sy});
         } else {
-            int cx = sx, cy = sy, nx = 0, ny = 0;
+            const int x2 = sx + kDx[s], y2 = sy + kDy[s];
+            int cx = sx, cy = sy;
             int prev_dir = s ^ 4;
             for (;;) {
-                const int s_from = s;
-                while (s < 15) {
-                    ++s;
-                    nx = cx + kDx[s & 7]; ny = cy + kDy[s & 7];
-                    if (set(nx, ny)) break;
-                }
-                s &= 7;
-                if ((unsigned)(s - 1) < (unsigned)s_from) mark_right(cx, cy);
-                else mark_plain(cx, cy);
+                const unsigned e = kFollow.next[code9(rp, rb, cx)][s];
+                s = e & 7;
+                mark(lr, rmg, cx, (e & 8) != 0);
                 if (s != prev_dir) {
                     points.push_back({cx, cy});
                     c.x0 = std::min(c.x0, cx); c.x1 = std::max(c.x1, cx);
                     c.y0 = std::min(c.y0, cy); c.y1 = std::max(c.y1, cy);
                     prev_dir = s;
                 }
+                // kDx[s], kDy[s] out of two packed constants (2 bits per direction, value + 1): the step is on the loop's latency chain
+                const int dy = (int)((0xA901u >> (2 * s)) & 3u) - 1;
+                const int nx = cx + (int)((0x901Au >> (2 * s)) & 3u) - 1, ny = cy + dy;
                 if (nx == sx && ny == sy && cx == x2 && cy == y2) break;
                 cx = nx; cy = ny;
+                rp += dy * rb; lr += dy * 2 * (ptrdiff_t)stride_; rmg += dy * (ptrdiff_t)gpr_;
                 s = (s + 4) & 7;
             }
         }
@@ -382,12 +451,14 @@ class BitScanner {
         contours.push_back(c);
     }
 
-    const uint32_t *b_;
-    int h_, w_, wpr_;
-    const uint64_t *rm_;
-    int gpr_;
-    uint32_t *t_ = nullptr, *r_ = nullptr;
-    Planes *pl_ = nullptr;
+    BitScratch &sc_;
+    int h_, wpr_, gpr_, stride_;
+    const uint32_t *img_;
+    uint32_t *lab_;
+
+  public:
+    std::vector<Pt> &points;
+    std::vector<Contour> &contours;  // in discovery order (cv2 reports them reversed)
 };
 
 double contour_area(const Pt *p, size_t n)
@@ -593,17 +664,44 @@ extern "C" int sv_find_grid_corners_bits_batch(const uint32_t *bits, int n, int 
     if (threads < 1) threads = 1;
     if (threads > n) threads = n;
     WorkerPool::instance().parallel_for(n, threads, [&](int i) {
-        BitScanner sc(bits + (size_t)i * H * (W >> 5), H, W);
+        BitScratch &scratch = BitScratch::get();
+        scratch.begin(H, W);
+        scratch.load_dense(bits + (size_t)i * H * (W >> 5));
+        BitScanner sc(scratch, H, W);
         found[i] = grid_corners_from(sc, H, W, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
     });
     return SV_OK;
+}
+
+// Expansion of a validated record with AVX-512 expand-loads: 16 words per instruction, zero fill included, so the image needs no
+// memset: the scratch image still holds the thread's previous frame exactly where `prev` (its row masks) has bits, and a 16-word chunk
+// is rewritten iff the old or the new frame has a word in it.  A chunk of a row's last group may reach past the row: it lands, as
+// zeros (mask bits beyond the row are validated to be clear), in pad words and in the first words of the next row(s), which are
+// processed after it, and the scratch image has 64 words of slack behind its last row.  prev is replaced by the new masks.
+__attribute__((target("avx512f"))) static void sparse_expand_avx512(const uint64_t *masks, uint64_t *prev, const uint32_t *val, int H, int gpr, uint32_t *row0,
+                                                                   int stride)
+{
+    for (int y = 0; y < H; y++) {
+        uint32_t *row = row0 + (size_t)y * stride;
+        for (int g = 0; g < gpr; g++) {
+            const uint64_t m = masks[(size_t)y * gpr + g], either = m | prev[(size_t)y * gpr + g];
+            prev[(size_t)y * gpr + g] = m;
+            if (!either) continue;
+            for (int j = 0; j < 4; j++) {
+                if (!((either >> (16 * j)) & 0xFFFF)) continue;
+                const __mmask16 mj = (__mmask16)(m >> (16 * j));
+                _mm512_storeu_si512(row + 64 * g + 16 * j, _mm512_maskz_expandloadu_epi32(mj, val));
+                val += __builtin_popcount((unsigned)mj);
+            }
+        }
+    }
 }
 
 // sparse record (include/sudoku_vision_hip.h, sv_pack_sparse_bits) -> dense bit image.  The record is validated before anything is
 // written from it (it crosses PCIe and may be stale, torn or built for another shape): 1 = expanded, 0 = the record overflowed its
 // capacity (n_values > cap_values: use the dense image), -1 = malformed (a mask bit beyond the row, more mask bits than values, or
 // a capacity that does not fit `avail` bytes; avail < 0 = unknown, trust cap_values).
-static int sparse_expand(const uint8_t *record, long avail, int H, int W, uint32_t *bits)
+static int sparse_expand(const uint8_t *record, long avail, int H, int W, uint32_t *bits, BitScratch *scratch)
 {
     const int wpr = W >> 5, gpr = (wpr + 63) / 64;
     const size_t head_bytes = 8 + 8 * (size_t)H * gpr;
@@ -624,11 +722,18 @@ static int sparse_expand(const uint8_t *record, long avail, int H, int W, uint32
             total += (size_t)__builtin_popcountll(m);
         }
     if (total != head[0]) return -1;
-    memset(bits, 0, (size_t)H * wpr * 4);
+    if (scratch) {                                               // the search's padded per-thread image, row masks taken over as they are
+        static const bool vec = __builtin_cpu_supports("avx512f");
+        scratch->begin(H, W, vec);
+        if (vec) { sparse_expand_avx512(masks, scratch->bmask.data(), val, H, gpr, scratch->row(0), scratch->stride); return 1; }
+        memcpy(scratch->bmask.data(), masks, 8 * (size_t)H * gpr);
+    } else {
+        memset(bits, 0, (size_t)H * wpr * 4);
+    }
     for (int y = 0; y < H; y++)
         for (int g = 0; g < gpr; g++) {
             uint64_t m = masks[(size_t)y * gpr + g];
-            uint32_t *row = bits + (size_t)y * wpr + 64 * g;
+            uint32_t *row = (scratch ? scratch->row(y) : bits + (size_t)y * wpr) + 64 * g;
             while (m) { row[__builtin_ctzll(m)] = *val++; m &= m - 1; }
         }
     return 1;
@@ -637,7 +742,7 @@ static int sparse_expand(const uint8_t *record, long avail, int H, int W, uint32
 extern "C" int sv_sparse_bits_expand(const uint8_t *record, int H, int W, uint32_t *bits)
 {
     if (!record || !bits || H <= 0 || W <= 0 || (W & 31) || ((uintptr_t)record & 7)) return sv_fail(SV_ERR_BAD_ARG, "sv_sparse_bits_expand: bad argument");
-    const int r = sparse_expand(record, -1, H, W, bits);
+    const int r = sparse_expand(record, -1, H, W, bits, nullptr);
     if (r == 0) return sv_fail(SV_ERR_BUFFER, "sv_sparse_bits_expand: the record overflowed its capacity");
     if (r < 0) return sv_fail(SV_ERR_BAD_ARG, "sv_sparse_bits_expand: malformed record (mask bits outside the row, or mask bits != n_values)");
     return SV_OK;
@@ -652,11 +757,10 @@ extern "C" int sv_find_grid_corners_sparse_batch(const uint8_t *records, long re
     if (threads < 1) threads = 1;
     if (threads > n) threads = n;
     WorkerPool::instance().parallel_for(n, threads, [&](int i) {
-        static thread_local std::vector<uint32_t> dense;
-        dense.resize((size_t)H * (W >> 5));
+        BitScratch &scratch = BitScratch::get();
         // overflowed or malformed (stale / torn / foreign) record: the caller searches the dense image of that frame instead
-        if (sparse_expand(records + (size_t)i * record_stride, record_stride, H, W, dense.data()) != 1) { found[i] = 2; return; }
-        BitScanner sc(dense.data(), H, W, reinterpret_cast<const uint64_t *>(records + (size_t)i * record_stride + 8));
+        if (sparse_expand(records + (size_t)i * record_stride, record_stride, H, W, nullptr, &scratch) != 1) { found[i] = 2; return; }
+        BitScanner sc(scratch, H, W);
         found[i] = grid_corners_from(sc, H, W, min_area_ratio, epsilon_ratio, corners + 8 * i) ? 1 : 0;
     });
     return SV_OK;
@@ -695,7 +799,10 @@ extern "C" int sv_find_contours_bits(const uint32_t *bits, int H, int W, int *po
                                      long *n_points, int *n_contours)
 {
     if (!bits || !n_points || !n_contours || H <= 0 || W <= 0 || (W & 31)) return sv_fail(SV_ERR_BAD_ARG, "sv_find_contours_bits: bad argument");
-    BitScanner sc(bits, H, W);
+    BitScratch &scratch = BitScratch::get();
+    scratch.begin(H, W);
+    scratch.load_dense(bits);
+    BitScanner sc(scratch, H, W);
     sc.run();
     *n_points = (long)sc.points.size();
     *n_contours = (int)sc.contours.size();

@@ -302,9 +302,28 @@ constexpr int MARCH_STRIP = 240;   // output columns per wave
 // frames instead of 531.  A lane's 4 pixels are a nibble; 4 lanes' nibbles are gathered by lane shifts into 16-bit stores (a strip of 240
 // pixels starts on a 16-bit boundary).
 // One (frame, band, strip) item = the work of one wave; sdl = that wave's delay line of blurred rows in LDS.
+// ---------------------------------------------------------------------------------------------------
+// The marching item, on packed f32 math since round 3 (same data flow and arithmetic as the scalar-f32 body of rounds 1-2, bit-identical
+// output, git history).  K1 is VALU-issue bound and on gfx950 a v_pk_{fma,add,mul}_f32 does two f32 operations in 2.0 ns of a SIMD's
+// issue time where two all-VGPR v_fma_f32 take 2.7 (tools/ubench_pk.hip, 4 waves per SIMD), so every stage whose work is elementwise
+// over a lane's 4 pixels runs on pixel PAIRS (the gray conversion, the vertical 1-4-6-4-1, its normalisation, the f32 column pass):
+// half the instructions.  The 11-tap f32 row pass is not elementwise -- pixel i needs v[i..i+10] of the 14 values around it, and a
+// packed operand must be an even-aligned register pair -- but its two lanes need not be at the same tap: with pixel 1 one tap BEHIND
+// pixel 0, both lanes of step j read the SAME value v[j] (a broadcast, free through op_sel) against the coefficient pair
+// (k_j, k_{j-1}): 12 packed steps give two pixels' 11-tap sums, each in cv2's order (lane 1's first step is fma(v1, k0, 0) = the
+// rounded product, its idle first and lane 0's idle last step multiply by 0: exact, all values are >= +0).  The horizontal
+// 1-4-6-4-1 stays scalar (its packed form costs more than it saves).  The threshold compare shifts its result straight into the
+// output nibble (v_cmp + v_addc: 2 instructions per pixel instead of 3-4), against src + 2 kept in the delay line.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+struct RowPairs { f32x2_t p[12]; };      // p[j] = (k_j, k_{j-1}), k_{-1} = k_11 = 0
+
+__device__ __forceinline__ f32x2_t pkfma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t bc2(float v) { return (f32x2_t){v, v}; }
+
 template <bool BITS>
 __device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *__restrict__ out,
-                                           const Taps11 &taps, int TH, int nstrips, int nbands, int item, f32x4_t (*sdl)[64])
+                                              const Taps11 &taps, const RowPairs &rp, int TH, int nstrips, int nbands, int item, f32x4_t (*sdl)[64])
 {
     const int lane = threadIdx.x & 63;
     const int strip = item % nstrips, band = (item / nstrips) % nbands, frame = item / (nstrips * nbands);
@@ -320,14 +339,19 @@ __device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, in
     const int N = (ye + 4) - qs + 1;                        // pushes: rows qs .. ye+4 (rows > H-1 are REPLICATE repeats of H-1)
     const int emit_from = yb + 5 - qs;                      // push index whose window centre is output row yb
     const int srcl_hi = (W - 1 - xs0) >> 2;                 // lane holding column W-1 (element 3 since W % 4 == 0)
+    const bool store_lane = lane >= 2 && lane < 62 && cx0 < W && (!BITS || ((lane - 2) & 3) == 0);
 
     auto load_raw = [&](int gy) -> u32x3 { return *(const u32x3 *)(img + (ptrdiff_t)sv_reflect101(gy, H) * pitch + ldx); };
-    // gray + horizontal 1-4-6-4-1 -> 4 un-normalised h values
+    // gray (pixel pairs) + horizontal 1-4-6-4-1 (scalar) -> 4 un-normalised h values
     auto hrow = [&](const u32x3 &d) -> f32x4_t {
-        float p0 = gray_f32((float)(d.a & 255), (float)((d.a >> 8) & 255), (float)((d.a >> 16) & 255));
-        float p1 = gray_f32((float)(d.a >> 24), (float)(d.b & 255), (float)((d.b >> 8) & 255));
-        float p2 = gray_f32((float)((d.b >> 16) & 255), (float)(d.b >> 24), (float)(d.c & 255));
-        float p3 = gray_f32((float)((d.c >> 8) & 255), (float)((d.c >> 16) & 255), (float)(d.c >> 24));
+        const f32x2_t cb = bc2(3735.f / 32768.f), cg = bc2(19235.f / 32768.f), cr = bc2(9798.f / 32768.f), half = bc2(0.5f);
+        const f32x2_t b01 = {(float)(d.a & 255), (float)(d.a >> 24)}, g01 = {(float)((d.a >> 8) & 255), (float)(d.b & 255)},
+                      r01 = {(float)((d.a >> 16) & 255), (float)((d.b >> 8) & 255)};
+        const f32x2_t b23 = {(float)((d.b >> 16) & 255), (float)((d.c >> 8) & 255)}, g23 = {(float)(d.b >> 24), (float)((d.c >> 16) & 255)},
+                      r23 = {(float)(d.c & 255), (float)(d.c >> 24)};
+        const f32x2_t y01 = __builtin_elementwise_floor(pkfma(b01, cb, pkfma(g01, cg, pkfma(r01, cr, half))));
+        const f32x2_t y23 = __builtin_elementwise_floor(pkfma(b23, cb, pkfma(g23, cg, pkfma(r23, cr, half))));
+        float p0 = y01[0], p1 = y01[1], p2 = y23[0], p3 = y23[1];
         if (edge_l) {            // REFLECT_101: columns -2,-1 are columns 2,1 (held by the next lane)
             const float n1 = lane_next(p1), n2 = lane_next(p2);
             if (cx0 == -4) { p2 = n2; p3 = n1; }
@@ -346,8 +370,10 @@ __device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, in
     };
     // blurred row (as f32) from the 5-row window, with the horizontal REPLICATE of the blurred image, and its f32 row pass
     auto finish_row = [&](const f32x4_t &a, const f32x4_t &b, const f32x4_t &c, const f32x4_t &d, const f32x4_t &e, f32x4_t &bfv, f32x4_t &rwv) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) bfv[i] = floorf(__builtin_fmaf(blur5(a[i], b[i], c[i], d[i], e[i]), 1.f / 256.f, 0.5f));
+        const f32x2_t four = bc2(4.f), six = bc2(6.f), inv = bc2(1.f / 256.f), half = bc2(0.5f);
+        const f32x2_t s01 = pkfma(six, c.xy, pkfma(four, b.xy + d.xy, a.xy + e.xy)), s23 = pkfma(six, c.zw, pkfma(four, b.zw + d.zw, a.zw + e.zw));
+        const f32x2_t n01 = __builtin_elementwise_floor(pkfma(s01, inv, half)), n23 = __builtin_elementwise_floor(pkfma(s23, inv, half));
+        bfv = (f32x4_t){n01[0], n01[1], n23[0], n23[1]};
         if (edge_l) {
             const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bfv[0]), 2));   // column 0 = lane 2, element 0
             if (cx0 < 0) { bfv[0] = v0; bfv[1] = v0; bfv[2] = v0; bfv[3] = v0; }
@@ -361,18 +387,16 @@ __device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, in
         for (int i = 0; i < 4; i++) { pv[i] = lane_prev(bfv[i]); nx[i] = lane_next(bfv[i]); }
         const float pp3 = lane_prev(pv[3]), nn0 = lane_next(nx[0]);
         const float v[14] = {pp3, pv[0], pv[1], pv[2], pv[3], bfv[0], bfv[1], bfv[2], bfv[3], nx[0], nx[1], nx[2], nx[3], nn0};
+        // pixels (0,1) over v[0..11], pixels (2,3) over v[2..13]; lane 1 of a pair runs one tap behind lane 0
+        f32x2_t d01 = bc2(v[0]) * rp.p[0], d23 = bc2(v[2]) * rp.p[0];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float acc = __fmul_rn(taps.k[0], v[i]);
-#pragma unroll
-            for (int j = 1; j < 11; j++) acc = __builtin_fmaf(v[i + j], taps.k[j], acc);
-            rwv[i] = acc;
+        for (int j = 1; j < 12; j++) {
+            d01 = pkfma(bc2(v[j]), rp.p[j], d01);
+            d23 = pkfma(bc2(v[2 + j]), rp.p[j], d23);
         }
+        rwv = (f32x4_t){d01[0], d01[1], d23[0], d23[1]};
     };
 
-    // Rings with static slots: the row loop is unrolled x12 (12 = lcm of the ring periods), so "which register holds row r"
-    // is a compile-time fact and no window is ever shifted: 12-slot ring of f32 row-pass results (11 in use), 6-slot ring of
-    // h rows (5 in use), PF = 4 image rows in flight.
     constexpr int PF = 4, NPH = 12;
     f32x4_t hw[6];
     hw[2] = hrow(load_raw(qs - 2)); hw[3] = hrow(load_raw(qs - 1)); hw[4] = hrow(load_raw(qs)); hw[5] = hrow(load_raw(qs + 1));
@@ -381,8 +405,10 @@ __device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, in
 #pragma unroll
     for (int i = 0; i < PF; i++) raw[i] = load_raw(qs + 2 + i);
 
-    f32x4_t cur_rw = {0.f, 0.f, 0.f, 0.f}, cur_bf = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t cur_bf = {0.f, 0.f, 0.f, 0.f};
     f32x4_t win[NPH];
+#pragma unroll
+    for (int k = 0; k < NPH; k++) win[k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     for (int base = 0; base < N; base += NPH) {
 #pragma unroll
@@ -394,32 +420,43 @@ __device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, in
                 raw[ph % PF] = load_raw(q + 2 + PF < H + 2 ? q + 2 + PF : H + 1);   // row that push i + PF will consume
                 if (q <= H - 1) {                                // wave-uniform; bottom REPLICATE pushes the last blurred row again
                     hw[ph % 6] = hrow(raw_cur);                  // h row q+2; rows q-2 .. q+1 sit in the 4 slots before it
-                    finish_row(hw[(ph + 2) % 6], hw[(ph + 3) % 6], hw[(ph + 4) % 6], hw[(ph + 5) % 6], hw[ph % 6], cur_bf, cur_rw);
-                }                                                // (no memory operation inside: the row loads stay in straight-line code)
+                    finish_row(hw[(ph + 2) % 6], hw[(ph + 3) % 6], hw[(ph + 4) % 6], hw[(ph + 5) % 6], hw[ph % 6], cur_bf, win[ph]);
+                } else {
+                    win[ph] = win[(ph + NPH - 1) % NPH];
+                }
                 if (i == 0) {
 #pragma unroll
-                    for (int k = 0; k < NPH; k++) win[k] = cur_rw;   // top REPLICATE: rows above the first one read the first one
+                    for (int k = 1; k < NPH; k++) win[k] = win[0];   // top REPLICATE: rows above the first one read the first one
                 }
-                win[ph] = cur_rw;
-                sdl[i & 7][lane] = cur_bf;
+                // the threshold compares rint(mean) with src + 2; both sides carry 2^23, which makes the rint an f32 add (round to
+                // nearest even at integer granularity) on the packed pipe
+                sdl[i & 7][lane] = cur_bf + 8388610.f;
                 if (i >= emit_from) {                            // emit output row yo; its window centre was pushed 5 pushes ago
                     const int yo = q - 5;
-                    const f32x4_t srcv = sdl[(i - 5) & 7][lane];
-                    u32 o = 0;
+                    const f32x4_t thr = sdl[(i - 5) & 7][lane];
+                    const f32x4_t &wc = win[(ph + NPH - 5) % NPH];
+                    f32x2_t a01 = bc2(taps.k[5]) * wc.xy, a23 = bc2(taps.k[5]) * wc.zw;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        float acc = __fmul_rn(taps.k[5], win[(ph + NPH - 5) % NPH][c]);
-#pragma unroll
-                        for (int j = 1; j <= 5; j++)
-                            acc = __builtin_fmaf(__fadd_rn(win[(ph + NPH - 5 + j) % NPH][c], win[(ph + 2 * NPH - 5 - j) % NPH][c]), taps.k[5 + j], acc);
-                        o |= (__fsub_rn(rintf(acc), srcv[c]) >= 2.f ? (BITS ? 1u : 255u) : 0u) << ((BITS ? 1 : 8) * c);
+                    for (int j = 1; j <= 5; j++) {
+                        const f32x4_t &wp = win[(ph + NPH - 5 + j) % NPH], &wm = win[(ph + 2 * NPH - 5 - j) % NPH];
+                        a01 = pkfma(wp.xy + wm.xy, bc2(taps.k[5 + j]), a01);
+                        a23 = pkfma(wp.zw + wm.zw, bc2(taps.k[5 + j]), a23);
                     }
+                    const f32x2_t r01 = a01 + bc2(8388608.f), r23 = a23 + bc2(8388608.f);      // 2^23 + rint(mean), exactly
+                    const float m0 = r01[0], m1 = r01[1], m2 = r23[0], m3 = r23[1];
+                    // src - mean <= -2  <=>  rint(mean) >= src + 2: each compare shifts its bit into the nibble (pixel 3 first)
+                    u32 o = 0;
+                    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(o) : "v"(m3), "v"(thr[3]) : "vcc");
+                    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(o) : "v"(m2), "v"(thr[2]) : "vcc");
+                    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(o) : "v"(m1), "v"(thr[1]) : "vcc");
+                    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(o) : "v"(m0), "v"(thr[0]) : "vcc");
                     if (BITS) {
                         const u32 a = o | (lane_next_u32(o) << 4);                     // lanes l, l+1
                         const u32 w16 = a | (lane_next_u32(lane_next_u32(a)) << 8);    // lanes l .. l+3
-                        if (lane >= 2 && lane < 62 && ((lane - 2) & 3) == 0 && cx0 < W)
-                            *(unsigned short *)(dst + (ptrdiff_t)yo * (W >> 3) + (cx0 >> 3)) = (unsigned short)w16;
-                    } else if (lane >= 2 && lane < 62 && cx0 < W) *(u32 *)(dst + (ptrdiff_t)yo * W + cx0) = o;
+                        if (store_lane) *(unsigned short *)(dst + (ptrdiff_t)yo * (W >> 3) + (cx0 >> 3)) = (unsigned short)w16;
+                    } else if (store_lane) {
+                        *(u32 *)(dst + (ptrdiff_t)yo * W + cx0) = ((o * 0x00204081u) & 0x01010101u) * 255u;   // nibble -> four 0/255 bytes
+                    }
                 }
             }
         }
@@ -428,13 +465,13 @@ __device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, in
 
 template <bool BITS>
 __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__ bgr, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
-                                                          u8 *__restrict__ out, Taps11 taps, int TH, int nstrips, int nbands, int nitems)
+                                                             u8 *__restrict__ out, Taps11 taps, RowPairs rp, int TH, int nstrips, int nbands, int nitems)
 {
-    __shared__ __attribute__((aligned(16))) f32x4_t sdl[4][8][64];   // per-wave delay line of blurred rows
+    __shared__ __attribute__((aligned(16))) f32x4_t sdl[4][8][64];   // per-wave delay line of blurred rows (+ 2: the compare's right-hand side)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int item = blockIdx.x * 4 + wave;
     if (item >= nitems) return;
-    march_item<BITS>(bgr, H, W, pitch, img_stride, out, taps, TH, nstrips, nbands, item, sdl[wave]);
+    march_item<BITS>(bgr, H, W, pitch, img_stride, out, taps, rp, TH, nstrips, nbands, item, sdl[wave]);
 }
 
 // BASELINE configs[4]'s fused threshold + warp launch for the device-only mode (corners known before K1 runs, so K1 and K2 are independent
@@ -442,7 +479,7 @@ __global__ __launch_bounds__(256) void k_preprocess_march(const u8 *__restrict__
 // k_warp_cells runs), laid out so that everything that touches frame f is dispatched together and on the same XCD (workgroup b runs on XCD
 // b % 8; frame f belongs to XCD f % 8) -- whichever of the two reads a frame region first leaves it in that XCD's L2 for the other.
 __global__ __launch_bounds__(256) void k_preprocess_warp_fused(const u8 *__restrict__ bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
-                                                               u8 *__restrict__ out, Taps11 taps, int TH, int nstrips, int nbands,
+                                                               u8 *__restrict__ out, Taps11 taps, RowPairs rp, int TH, int nstrips, int nbands,
                                                                const double *__restrict__ minv, u8 *__restrict__ cells)
 {
     __shared__ __attribute__((aligned(16))) f32x4_t sdl[4][8][64];
@@ -452,7 +489,7 @@ __global__ __launch_bounds__(256) void k_preprocess_warp_fused(const u8 *__restr
     if (frame >= n) return;
     if (within < k1_wgs) {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), local = within * 4 + wave;
-        if (local < items) march_item<false>(bgr, H, W, pitch, img_stride, out, taps, TH, nstrips, nbands, frame * items + local, sdl[wave]);
+        if (local < items) march_item<false>(bgr, H, W, pitch, img_stride, out, taps, rp, TH, nstrips, nbands, frame * items + local, sdl[wave]);
     } else {
         sv_k2::warp_cells_item(bgr, H, W, pitch, img_stride, minv, cells, frame, within - k1_wgs, cl);
     }
@@ -528,11 +565,18 @@ __global__ void k_adaptive_threshold(const u8 *__restrict__ src, int H, int W, F
 // requirements hold
 static int k1_algo() { static const int a = [] { const char *e = getenv("SV_K1_ALGO"); return e ? atoi(e) : 0; }(); return a; }
 
+static RowPairs row_pairs(const Taps11 &t)
+{
+    RowPairs rp;
+    for (int j = 0; j < 12; j++) rp.p[j] = (f32x2_t){j < 11 ? t.k[j] : 0.f, j > 0 ? t.k[j - 1] : 0.f};
+    return rp;
+}
+
 // the march kernel's launch shape for n frames
 static void march_shape(int n, int H, int W, int &nstrips, int &nbands, int &TH)
 {
     nstrips = (W + MARCH_STRIP - 1) / MARCH_STRIP;
-    nbands = (12288 + n * nstrips - 1) / (n * nstrips);      // ~3 rounds of 4 waves per SIMD on 256 CUs (flat between 4k and 20k waves)
+    nbands = (12288 + n * nstrips - 1) / (n * nstrips);      // ~3 rounds of 4 waves per SIMD on 256 CUs (flat from 4k to 20k waves, tools/dev/k1_shape_sweep.py)
     if (nbands > H / 32) nbands = H / 32;
     if (nbands < 1) nbands = 1;
     TH = (H + nbands - 1) / nbands;
@@ -551,7 +595,7 @@ int svk_preprocess_bits(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff
     int nstrips, nbands, TH;
     march_shape(n, H, W, nstrips, nbands, TH);
     const int nitems = n * nstrips * nbands;
-    hipLaunchKernelGGL(k_preprocess_march<true>, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, (u8 *)bits, t, TH, nstrips, nbands, nitems);
+    hipLaunchKernelGGL(k_preprocess_march<true>, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, (u8 *)bits, t, row_pairs(t), TH, nstrips, nbands, nitems);
     SV_LAUNCH_CHECK("k_preprocess_march<bits>");
     return SV_OK;
 }
@@ -568,7 +612,7 @@ int svk_preprocess_warp_fused(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, p
     march_shape(n, H, W, nstrips, nbands, TH);
     const long per_frame = (nstrips * nbands + 3) / 4 + 81;
     const long blocks = (long)((n + 7) / 8) * per_frame * 8;
-    hipLaunchKernelGGL(k_preprocess_warp_fused, dim3((unsigned)blocks), dim3(256), 0, s, bgr, n, H, W, pitch, img_stride, binary, t, TH, nstrips, nbands, minv, cells);
+    hipLaunchKernelGGL(k_preprocess_warp_fused, dim3((unsigned)blocks), dim3(256), 0, s, bgr, n, H, W, pitch, img_stride, binary, t, row_pairs(t), TH, nstrips, nbands, minv, cells);
     SV_LAUNCH_CHECK("k_preprocess_warp_fused");
     return SV_OK;
 }
@@ -591,7 +635,7 @@ int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pi
             int nstrips, nbands, TH;
             march_shape(n, H, W, nstrips, nbands, TH);
             const int nitems = n * nstrips * nbands;
-            hipLaunchKernelGGL(k_preprocess_march<false>, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, TH, nstrips, nbands, nitems);
+            hipLaunchKernelGGL(k_preprocess_march<false>, dim3((nitems + 3) / 4), dim3(256), 0, s, bgr, H, W, pitch, img_stride, binary, t, row_pairs(t), TH, nstrips, nbands, nitems);
         } else {
             hipLaunchKernelGGL((k_preprocess_f32<64, 64, 512, 3, 2>), grid, dim3(512), 0, s, bgr, H, W, pitch, img_stride, binary, t, aligned4);
         }

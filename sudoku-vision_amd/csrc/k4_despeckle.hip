@@ -11,9 +11,14 @@
 //
 // One wave per tile, one lane per tile row, the row held as a 64-bit mask.  Seeds = foreground pixels on the
 // tile's outer ring; flood fill by Jacobi iteration: within a row a seed spreads along its run with one
-// carry-propagating add per direction, between rows through DPP lane shifts.  Stops when a wave-wide ballot
-// sees no change (or after MAX_IT iterations, in which case the tile is left untouched).  Two passes with the
-// tile grid offset by (32,32) catch specks that straddle a tile edge of the first pass.
+// carry-propagating add per direction, between rows through DPP lane shifts -- one row per iteration.  A tile crossed by
+// the grid's vertical lines needed up to 64 such iterations (38 % of a synthetic frame's tiles, most of the kernel's time), so
+// since round 3 the fill alternates orientation: after every iteration the reached set is transposed (64x64 bits across the
+// wave: one v_permlane32_swap, then five exchange steps of shuffle + v_alignbit + v_bfi per word) and the next iteration runs
+// on the transposed tile, where the columns are the carry-filled direction.  A grid tile converges in 4-6 iterations instead
+// of 64.  Stops when an iteration changes nothing (a fixed point of either orientation is one of both: each iteration also
+// steps once across its slow direction) or after MAX_IT iterations, in which case the tile is left untouched.  Two passes
+// with the tile grid offset by (32,32) catch specks that straddle a tile edge of the first pass.
 #include "sv_device.h"
 #include "sv_internal.h"
 
@@ -45,6 +50,64 @@ __device__ __forceinline__ u64 fill_runs(u64 f, u64 g)
 
 constexpr int T = 64, MAX_IT = 96;
 
+// 64x64 bit transpose across the wave: lane r holds row r (bit c = column c) -> lane c holds column c (bit r).
+// Scale 32: lanes r < 32 exchange their high word with the low word of lane r + 32 (v_permlane32_swap).  Scale k < 32, per 32-bit
+// word: with p = the word of lane r ^ k, lane r keeps its blocks on the diagonal and takes the partner's off-diagonal blocks moved
+// by k bits -- rotr(p, 32 - k) for (r & k) == 0, rotr(p, k) otherwise (the bits a rotation wraps around fall under the kept mask).
+template <int K>
+__device__ __forceinline__ u32 xchg(u32 v)          // value of lane ^ K
+{
+    if (K == 1) return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, true);
+    if (K == 2) return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true);
+    return (u32)__builtin_amdgcn_ds_swizzle((int)v, (K << 10) | 0x1F);    // xor mask K within each half of the wave
+}
+template <int K>
+__device__ __forceinline__ void transpose_step(u32 &lo, u32 &hi, int lane)
+{
+    constexpr u32 M = K == 16 ? 0x0000FFFFu : K == 8 ? 0x00FF00FFu : K == 4 ? 0x0F0F0F0Fu : K == 2 ? 0x33333333u : 0x55555555u;
+    const bool upper = (lane & K) != 0;
+    const u32 keep = upper ? ~M : M, rot = upper ? K : 32 - K;
+    const u32 pl = xchg<K>(lo), ph = xchg<K>(hi);
+    lo = (lo & keep) | (__builtin_amdgcn_alignbit(pl, pl, rot) & ~keep);
+    hi = (hi & keep) | (__builtin_amdgcn_alignbit(ph, ph, rot) & ~keep);
+}
+__device__ __forceinline__ u64 transpose64(u64 v, int lane)
+{
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    const auto sw = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);   // lo of lanes 32..63 <-> hi of lanes 0..31
+    lo = sw[0]; hi = sw[1];
+    transpose_step<16>(lo, hi, lane);
+    transpose_step<8>(lo, hi, lane);
+    transpose_step<4>(lo, hi, lane);
+    transpose_step<2>(lo, hi, lane);
+    transpose_step<1>(lo, hi, lane);
+    return ((u64)hi << 32) | lo;
+}
+
+// The pixels of tile f (lane = row) that are 8-connected to the tile's outer ring; f itself if the fill did not converge.
+__device__ __forceinline__ u64 ring_connected(u64 f, int lane)
+{
+    const u64 ring = (lane == 0 || lane == T - 1) ? ~0ull : 0x8000000000000001ull;      // the same mask in either orientation
+    u64 g = fill_runs(f, f & ring);
+    if (!__any(f != g)) return f;                                     // everything hangs on the ring already (or the tile is empty)
+    const u64 ft = transpose64(f, lane);
+    u64 cur = f;                                                      // the tile in the orientation g is in
+    bool transposed = false, converged = false;
+    for (int it = 0; it < MAX_IT; it++) {
+        const u64 nb = g | lane_shift_up(g) | lane_shift_down(g);
+        const u64 seeds = cur & (nb | (nb << 1) | (nb >> 1));          // 8-connectivity
+        const u64 g2 = fill_runs(cur, g | seeds);
+        const bool changed = g2 != g;
+        g = g2;
+        if (!__any(changed)) { converged = true; break; }
+        g = transpose64(g, lane);
+        transposed = !transposed;
+        cur = transposed ? ft : f;
+    }
+    if (!converged) return f;
+    return transposed ? transpose64(g, lane) : g;
+}
+
 __global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u8 *__restrict__ dst, u32 *__restrict__ packed, int H, int W,
                                                    int ox, int oy, int tiles_x, int tiles_y, long ntiles)
 {
@@ -72,18 +135,7 @@ __global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u
             if (x >= 0 && x < W && row[x]) f |= 1ull << k;
         }
     }
-    const u64 ring = (lane == 0 || lane == T - 1) ? ~0ull : 0x8000000000000001ull;
-    u64 g = fill_runs(f, f & ring);
-    bool converged = false;
-    for (int it = 0; it < MAX_IT; it++) {
-        const u64 nb = g | lane_shift_up(g) | lane_shift_down(g);
-        const u64 seeds = f & (nb | (nb << 1) | (nb >> 1));          // 8-connectivity
-        const u64 g2 = fill_runs(f, g | seeds);
-        const bool changed = g2 != g;
-        g = g2;
-        if (!__any(changed)) { converged = true; break; }
-    }
-    const u64 keep = converged ? g : f;
+    const u64 keep = ring_connected(f, lane);
     if (packed) {                     // bit-packed result (1 bit per pixel, LSB first, W/32 words per row) for the D2H copy
         if (row_ok) {
             u32 *prow = packed + (frame * H + y) * (long)(W >> 5);
@@ -123,18 +175,7 @@ __global__ __launch_bounds__(256) void k_despeckle_bits(u32 *__restrict__ bits, 
     u32 *row = bits + (frame * H + (row_ok ? y : 0)) * (long)wpr;
     const bool ok0 = row_ok && k0 >= 0 && k0 < wpr, ok1 = row_ok && k0 + 1 < wpr;
     const u64 f = (ok0 ? (u64)row[k0] : 0ull) | (ok1 ? (u64)row[k0 + 1] << 32 : 0ull);
-    const u64 ring = (lane == 0 || lane == T - 1) ? ~0ull : 0x8000000000000001ull;
-    u64 g = fill_runs(f, f & ring);
-    bool converged = false;
-    for (int it = 0; it < MAX_IT; it++) {
-        const u64 nb = g | lane_shift_up(g) | lane_shift_down(g);
-        const u64 seeds = f & (nb | (nb << 1) | (nb >> 1));          // 8-connectivity
-        const u64 g2 = fill_runs(f, g | seeds);
-        const bool changed = g2 != g;
-        g = g2;
-        if (!__any(changed)) { converged = true; break; }
-    }
-    const u64 keep = converged ? g : f;
+    const u64 keep = ring_connected(f, lane);
     if (keep == f) return;
     if (ok0 && (u32)keep != (u32)f) row[k0] = (u32)keep;
     if (ok1 && (u32)(keep >> 32) != (u32)(f >> 32)) row[k0 + 1] = (u32)(keep >> 32);
@@ -165,11 +206,20 @@ __global__ __launch_bounds__(1024) void k_pack_sparse(const u32 *__restrict__ bi
     u8 *rec = records + (size_t)blockIdx.x * stride;
     u64 *masks = (u64 *)(rec + 8);
     u32 *values = (u32 *)(rec + 8 + 8 * (size_t)G);
-    for (int g = wave; g < G; g += 16) {
-        const int y = g / gpr, k = (g - y * gpr) * 64 + lane;
-        const u32 w = k < wpr ? fb[(size_t)y * wpr + k] : 0u;
-        const u64 m = __ballot(w != 0);
-        if (lane == 0) { masks[g] = m; cnt[g] = (u32)__popcll(m); }
+    // (U row groups per wave per trip, their loads issued together: one load per trip left the kernel waiting out a full memory latency 68 times)
+    constexpr int U = 8;
+    for (int g0 = wave * U; g0 < G; g0 += 16 * U) {
+        u32 w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int g = g0 + u, y = g / gpr, k = (g - y * gpr) * 64 + lane;
+            w[u] = (g < G && k < wpr) ? fb[(size_t)y * wpr + k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 m = __ballot(w[u] != 0);
+            if (lane == 0 && g0 + u < G) { masks[g0 + u] = m; cnt[g0 + u] = (u32)__popcll(m); }
+        }
     }
     __syncthreads();
     const int per = (G + 1023) / 1024, lo = tid * per, hi = lo + per < G ? lo + per : G;
@@ -188,12 +238,21 @@ __global__ __launch_bounds__(1024) void k_pack_sparse(const u32 *__restrict__ bi
     u32 run = base + incl - mine;
     for (int i = lo; i < hi; i++) { const u32 c = cnt[i]; cnt[i] = run; run += c; }
     __syncthreads();
-    for (int g = wave; g < G; g += 16) {
-        const int y = g / gpr, k = (g - y * gpr) * 64 + lane;
-        const u32 w = k < wpr ? fb[(size_t)y * wpr + k] : 0u;
-        const u64 m = __ballot(w != 0);
-        const u32 pos = cnt[g] + (u32)__popcll(m & ((1ull << lane) - 1));
-        if (w && pos < cap_values) values[pos] = w;
+    for (int g0 = wave * U; g0 < G; g0 += 16 * U) {
+        u32 w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int g = g0 + u, y = g / gpr, k = (g - y * gpr) * 64 + lane;
+            w[u] = (g < G && k < wpr) ? fb[(size_t)y * wpr + k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 m = __ballot(w[u] != 0);
+            if (w[u]) {                                          // (a non-zero word implies g0 + u < G)
+                const u32 pos = cnt[g0 + u] + (u32)__popcll(m & ((1ull << lane) - 1));
+                if (pos < cap_values) values[pos] = w[u];
+            }
+        }
     }
     if (tid == 0) { ((u32 *)rec)[0] = total; ((u32 *)rec)[1] = cap_values; }
 }

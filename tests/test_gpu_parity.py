@@ -313,6 +313,63 @@ def test_tiny_and_odd_images(ctx):
         assert (got[0] == o.preprocess_for_grid_detection(img[0])).all(), (H, W)
 
 
+def _despeckle_np(img):
+    """numpy/scipy statement of sv_despeckle_u8: two passes over 64x64 tiles (grid origin (0,0), then (-32,-32)); in every tile the
+    8-connected components of the tile's own pixels that touch none of the tile's outermost pixels are erased."""
+    from scipy import ndimage
+    out = (img > 0).copy()
+    H, W = out.shape
+    for off in (0, 32):
+        for y0 in range(-off, H, 64):
+            for x0 in range(-off, W, 64):
+                ya, yb, xa, xb = max(y0, 0), min(y0 + 64, H), max(x0, 0), min(x0 + 64, W)
+                t = out[ya:yb, xa:xb]
+                if not t.any():
+                    continue
+                lab, n = ndimage.label(t, structure=np.ones((3, 3)))
+                ring = np.zeros_like(t)
+                if ya == y0:
+                    ring[0] = True
+                if yb == y0 + 64:
+                    ring[-1] = True
+                if xa == x0:
+                    ring[:, 0] = True
+                if xb == x0 + 64:
+                    ring[:, -1] = True
+                keep = np.unique(lab[ring & t])
+                t &= np.isin(lab, keep[keep > 0])
+    return out
+
+
+def test_despeckle_equals_tile_labelling(ctx):
+    """sv_despeckle_u8 / sv_despeckle_bits against a per-tile connected-component labelling in scipy, pixel for pixel: a synthetic frame,
+    blobs, thin diagonals and a grid rotated by 45 degrees (the slow direction of either fill orientation), a frame of vertical and one of
+    horizontal hairlines.  Exercises the transposing flood fill (tiles whose components reach deep into the tile along columns)."""
+    from scipy import ndimage
+    rs = np.random.RandomState(11)
+    H, W = 384, 512
+    imgs = []
+    frames, _, _ = _frames(1, H, W, seed=52)
+    imgs.append(ctx.preprocess(frames)[0].cpu().numpy() > 0)
+    g = ndimage.gaussian_filter(rs.uniform(size=(H, W)), 1.5)
+    imgs.append(g > np.quantile(g, 0.55))
+    yy, xx = np.mgrid[:H, :W]
+    imgs.append(((yy + xx) % 23 == 0) | ((yy - xx) % 31 == 0))                          # 1-px diagonals, both directions
+    imgs.append((((yy + xx) % 41 < 3) | ((yy - xx) % 41 < 3)) & (abs(yy - H // 2) + abs(xx - W // 2) < 150))   # 45-degree grid in a diamond
+    imgs.append((xx % 7 == 3) & (yy % 50 > 2))                                           # vertical hairlines, broken every 50 rows
+    imgs.append((yy % 7 == 3) & (xx % 50 > 2))                                           # horizontal hairlines
+    imgs.append(rs.uniform(size=(H, W)) < 0.3)                                           # dense noise
+    d = torch.from_numpy((np.stack(imgs) * 255).astype(np.uint8)).cuda()
+    got = ctx.despeckle(d).cpu().numpy() > 0
+    bits = torch.from_numpy(np.packbits(np.stack(imgs), axis=2, bitorder="little").view(np.int32)).cuda()
+    got_bits = np.unpackbits(ctx.despeckle_bits(bits).cpu().numpy().view(np.uint8).reshape(len(imgs), H, -1), axis=2, bitorder="little").astype(bool)
+    for k, img in enumerate(imgs):
+        want = _despeckle_np(img)
+        assert np.array_equal(got[k], want), k
+        assert np.array_equal(got_bits[k], want), k
+    assert (got[6] != imgs[6]).any() and (got[1] != imgs[1]).any() and (got[0] != imgs[0]).any()   # something was erased at all
+
+
 def test_despeckle_preserves_grid_search(ctx):
     """The despeckle accelerator erases only whole components that sit strictly inside a 64x64 tile, and the host
     corner search returns the same answer on the filtered image (synthetic frames + adversarial blob images)."""

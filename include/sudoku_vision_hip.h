@@ -49,7 +49,7 @@ typedef enum sv_status {
 
 /* ---- library / context ------------------------------------------------------------------------ */
 
-int sv_version(void);                               /* ABI version, currently 1 */
+int sv_version(void);                               /* ABI version, currently 2 (2: sv_timing_end takes the array length; sv_ctx_set_cnn_kernels) */
 const char *sv_last_error(void);                    /* thread-local, never NULL */
 
 /* Creates a context on HIP device `device` (replaces nothing: the reference keeps no state except
@@ -57,12 +57,28 @@ const char *sv_last_error(void);                    /* thread-local, never NULL 
 int sv_ctx_create(int device, sv_ctx **out);
 int sv_ctx_destroy(sv_ctx *ctx);
 
-/* Arithmetic of the CNN's conv2/fc1 (BASELINE.json configs[1] vs configs[4]).  SV_PREC_F32 (default): exact f32 MFMA,
- * logits within 1e-4 of the PyTorch-CPU model.  SV_PREC_BF16: bf16 operands, f32 accumulation (v_mfma_f32_16x16x32_bf16);
- * parity target = predicted digit indices.  Applies to sv_cnn_forward_cells_u8 and sv_frames_to_digits. */
+/* Arithmetic of the CNN's conv2/fc1 (BASELINE.json configs[1] vs configs[4]).  SV_PREC_F32 (default): f32-grade results, logits
+ * within 1e-4 of the PyTorch-CPU model (which kernels deliver them: sv_ctx_set_cnn_kernels below).  SV_PREC_BF16: bf16 operands, f32
+ * accumulation (v_mfma_f32_16x16x32_bf16); parity target = predicted digit indices.  Applies to sv_cnn_forward_cells_u8 and
+ * sv_frames_to_digits. */
 #define SV_PREC_F32 0
 #define SV_PREC_BF16 1
 int sv_ctx_set_precision(sv_ctx *ctx, int precision);
+
+/* Which kernels compute the SV_PREC_F32 forward.  Nothing in the process environment influences this.
+ *   SV_CNN_AUTO (default)  csrc/k3_cnn_h2.hip -- every f32 operand as a pair of f16 halves (22 significant bits) on the f16 matrix pipe,
+ *                          f32 accumulation, logits ~1e-6 from an exact evaluation -- whenever that is safe, else csrc/k3_cnn.hip's f32-MFMA
+ *                          kernels.  "Safe" = inputs, conv1 activations and features stay inside f16's range (|v| < 65,504):
+ *                          sv_load_weights_f32 bounds the activations from the weights (worst case over inputs in [-1, 1], which is what
+ *                          8-bit cells become), and an f32 input batch (sv_cnn_forward_f32) is range-checked on the device per call -- out
+ *                          of range, NaN/Inf or all below 2^-10, it takes the f32 kernels, with no host synchronisation either way.  So
+ *                          the entry points accept what ml/model.py:34-42 accepts: any f32.
+ *   SV_CNN_F16PAIR         the f16-pair kernels unconditionally (inputs/activations beyond 65,504 then overflow to inf)
+ *   SV_CNN_F32MFMA         the f32-MFMA kernels unconditionally (true f32 throughout; about 4x slower) */
+#define SV_CNN_AUTO 0
+#define SV_CNN_F16PAIR 1
+#define SV_CNN_F32MFMA 2
+int sv_ctx_set_cnn_kernels(sv_ctx *ctx, int which);
 
 /* Pre-sizes the context's scratch for batches of up to `max_cells` cells so that later calls do
  * no hipMalloc (needed before hipGraph capture). */
@@ -75,11 +91,12 @@ int sv_ctx_reserve(sv_ctx *ctx, long max_cells);
  * milliseconds and launches. */
 #define SV_TIMED_KERNELS 5
 int sv_timing_begin(sv_ctx *ctx);
-int sv_timing_end(sv_ctx *ctx, double *ms_total /*host, SV_TIMED_KERNELS*/, long *launches /*host, SV_TIMED_KERNELS*/);
+/* n_kernels = the length of the caller's two arrays (SV_TIMED_KERNELS of the header it was built against): ids >= n_kernels are not reported. */
+int sv_timing_end(sv_ctx *ctx, double *ms_total /*host, n_kernels*/, long *launches /*host, n_kernels*/, int n_kernels);
 
-/* Measurement aid: which conv/fc kernels sv_cnn_forward_* / sv_frames_to_digits launch in this process (SV_CONV_ALGO environment
- * variable; default 4 = f16 hi/lo operand pairs on the f16 matrix pipe, csrc/k3_cnn_h2.hip) and the matrix instructions they
- * issue per 28x28 cell: v_mfma_f32_16x16x4_f32 (2048 FLOP each) for conv2 and conv1 (0 = conv1 on the VALU) of the f32-MFMA
+/* Measurement aid: which conv/fc kernels sv_cnn_forward_cells_u8 / sv_frames_to_digits launch on this context with the weights
+ * loaded (4 = f16 hi/lo operand pairs on the f16 matrix pipe, csrc/k3_cnn_h2.hip; 0 = f32 MFMA, csrc/k3_cnn.hip) and the matrix
+ * instructions they issue per 28x28 cell: v_mfma_f32_16x16x4_f32 (2048 FLOP each) for conv2 and conv1 (0 = conv1 on the VALU) of the f32-MFMA
  * kernels, or v_mfma_f32_16x16x32_f16 (16384 FLOP each) for the conv kernel and the fc kernel of the default pair.  bench.py prices
  * a kernel's roofline fraction on the work it issues against the peak of the pipe it issues it on. */
 int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_f32_conv2_per_cell, int *mfma_f32_conv1_per_cell,
@@ -112,14 +129,6 @@ int sv_adaptive_threshold_u8(sv_ctx *ctx, const uint8_t *src /*dev, n*H*W*/, int
 int sv_preprocess_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch,
                      ptrdiff_t img_stride, uint8_t *binary /*dev, n*H*W*/, void *stream);
 
-/* sv_preprocess_u8 in its matrix-pipe formulation (csrc/k1_threshold_mm.hip: the four separable passes as Toeplitz GEMMs on the f16
- * MFMA, the 11x11 float mean approximated and every pixel it cannot decide re-decided with cv2's exact sequence).  Same output, bit
- * for bit; slower than the default kernel on MI355X (1.30 vs 0.64 ms per 256 1080p frames) -- an independent second implementation
- * for cross-checking.  mean (optional, dev, n*H*W floats): the approximate local mean per pixel, for the tests' error measurement.
- * Needs H, W >= 16, W % 16 == 0, 4-byte aligned frames, 16-byte aligned output: SV_ERR_UNSUPPORTED otherwise. */
-int sv_preprocess_mm_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
-                        uint8_t *binary /*dev, n*H*W*/, float *mean /*dev or NULL*/, void *stream);
-
 /* BASELINE configs[4], "fused threshold/warp" for the device-only mode: preprocess_for_grid_detection (cv/preprocess.py:57-65) and
  * warp_perspective + extract_cells (cv/grid.py:94-133, cv/extract.py:13-56) of the same frames in ONE launch, for callers that know the
  * corners before thresholding (a tracker, the benchmark's generator corners).  Same outputs as sv_preprocess_u8 + sv_warp_cells_u8.
@@ -127,12 +136,6 @@ int sv_preprocess_mm_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, i
  * Needs H, W >= 16, W % 4 == 0 and 4-byte aligned frames / binary: SV_ERR_UNSUPPORTED otherwise. */
 int sv_preprocess_warp_cells_u8(sv_ctx *ctx, const uint8_t *bgr /*dev*/, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride,
                                 uint8_t *binary /*dev, n*H*W*/, const double *minv /*dev, n*9*/, uint8_t *cells /*dev, n*81*784*/, void *stream);
-
-/* Diagnostics for sv_preprocess_mm_u8: the number of
- * pixels, since the previous call, whose approximate local mean was too close to the threshold to decide and which were
- * therefore decided with cv2's exact float sequence.  The first call on a context switches the counter on and returns 0.
- * capacity: reserved (0).  Synchronises the device. */
-int sv_preprocess_stats(sv_ctx *ctx, unsigned *ambiguous, unsigned long *capacity);
 
 /* preprocess_for_grid_detection() with the binary written as 1 bit per pixel (bit = pixel != 0, LSB = leftmost, W/32
  * words per row, rows dense): the form the host corner search reads (sv_find_grid_corners_bits_batch) when nothing
@@ -271,9 +274,9 @@ int sv_warp_cells_u8(sv_ctx *ctx, const uint8_t *frames /*dev*/, int n, int H, i
 
 /* DigitCNN.forward, ml/model.py:34-42 (eval mode): x f32 [B,1,28,28] -> logits f32 [B,10].
  * digits (argmax, pipeline/run.py:142) and conf (softmax[argmax], :141-143) may be NULL.
- * Range: the default kernels (csrc/k3_cnn_h2.hip) carry inputs and activations as f16 pairs (f32-grade accuracy, ~1e-6 on the
- * logits): their magnitudes must stay below 65,504.  The model's inputs are in [-1, 1] and its activations below ~100 with any
- * trained weights; SV_CONV_ALGO=2 (environment, read once per process) selects the f32-MFMA kernels, which have no such limit. */
+ * Any finite f32 input is accepted: a batch outside the range the default kernels carry exactly is computed by the f32-MFMA kernels
+ * (sv_ctx_set_cnn_kernels).  A cell holding NaN/Inf does not disturb the other cells of its batch; its own logits are unspecified (the
+ * reference yields NaN there; ReLU and max-pool here are IEEE maxNum, which drops a NaN). */
 int sv_cnn_forward_f32(sv_ctx *ctx, const float *x /*dev*/, long B, float *logits /*dev, B*10*/,
                        uint8_t *digits /*dev, B, or NULL*/, float *conf /*dev, B, or NULL*/,
                        void *stream);

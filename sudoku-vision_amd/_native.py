@@ -4,6 +4,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsudokuvision_hip.so")
+# test-only superset build (csrc/Makefile, include/sudoku_vision_xcheck.h): independent second implementations for cross-checks.  Loaded by
+# tests/ and tools/ through lib_xcheck(); never by the package itself.
+XCHECK_LIB_PATH = os.path.join(_HERE, "csrc", "libsudokuvision_xcheck.so")
+ABI_VERSION = 2
 
 SV_OK = 0
 ERR_NAMES = {-1: "SV_ERR_BAD_ARG", -2: "SV_ERR_HIP", -3: "SV_ERR_NO_WEIGHTS", -4: "SV_ERR_UNSUPPORTED",
@@ -21,7 +25,8 @@ SIGNATURES = {
     "sv_ctx_set_precision": [_p, _i],
     "sv_load_weights_f32": [_p, _p],
     "sv_timing_begin": [_p],
-    "sv_timing_end": [_p, _p, _p],
+    "sv_timing_end": [_p, _p, _p, _i],
+    "sv_ctx_set_cnn_kernels": [_p, _i],
     "sv_conv_kernel_info": [_p, _p, _p, _p, _p, _p],
     "sv_gray_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
     "sv_blur_u8": [_p, _p, _i, _i, _i, _i, _p, _p],
@@ -30,9 +35,7 @@ SIGNATURES = {
     "sv_solve_sudoku": [_p, _p, _p],
     "sv_despeckle_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
     "sv_preprocess_bits_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p],
-    "sv_preprocess_stats": [_p, _p, _p],
     "sv_preprocess_warp_cells_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p, _p],
-    "sv_preprocess_mm_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p],
     "sv_despeckle_bits": [_p, _p, _i, _i, _i, _p],
     "sv_copy_to_pinned_host": [_p, _p, _p, C.c_size_t, _p],
     "sv_sparse_bits_record_bytes": [_i, _i, _l],
@@ -68,6 +71,12 @@ SIGNATURES = {
     "sv_frames_to_digits": [_p, _p, _i, _i, _i, _pd, _pd, _p, _i, _p, _p, _p, _p, _p],
 }
 _RESTYPES = {"sv_last_error": C.c_char_p, "sv_sparse_bits_record_bytes": C.c_long}
+# what libsudokuvision_xcheck.so exports on top of SIGNATURES (include/sudoku_vision_xcheck.h)
+XCHECK_SIGNATURES = {
+    "sv_preprocess_stats": [_p, _p, _p],
+    "sv_preprocess_mm_u8": [_p, _p, _i, _i, _i, _pd, _pd, _p, _p, _p],
+    "svx_ctx_set_fc_frame_kernel": [_p, _i],
+}
 
 
 
@@ -78,6 +87,7 @@ class JpegInfo(C.Structure):
 
 
 _lib = None
+_xlib = None
 
 
 class NativeError(RuntimeError):
@@ -94,16 +104,33 @@ def lib():
             raise NativeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C sudoku-vision_amd/csrc`.  There is no CPU fallback.")
-        handle = C.CDLL(LIB_PATH)
-        for name, args in SIGNATURES.items():
-            fn = getattr(handle, name)  # AttributeError = ABI mismatch, let it surface
-            fn.argtypes = args
-            fn.restype = _RESTYPES.get(name, C.c_int)
-        _lib = handle
+        _lib = _bind(C.CDLL(LIB_PATH), SIGNATURES)
     return _lib
 
 
-def check(rc: int, what: str = ""):
+def _bind(handle, signatures):
+    for name, args in signatures.items():
+        fn = getattr(handle, name)  # AttributeError = ABI mismatch, let it surface
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    v = handle.sv_version()
+    if v != ABI_VERSION:
+        raise NativeError(f"{getattr(handle, '_name', 'library')}: ABI version {v}, this package binds version {ABI_VERSION}: rebuild (make -C sudoku-vision_amd/csrc)")
+    return handle
+
+
+def lib_xcheck():
+    """The test-only superset library (cross-check kernels).  For tests/ and tools/ only."""
+    global _xlib
+    if _xlib is None:
+        import torch  # noqa: F401
+        if not os.path.exists(XCHECK_LIB_PATH):
+            raise NativeError(f"{XCHECK_LIB_PATH} is missing: make -C sudoku-vision_amd/csrc libsudokuvision_xcheck.so")
+        _xlib = _bind(C.CDLL(XCHECK_LIB_PATH), {**SIGNATURES, **XCHECK_SIGNATURES})
+    return _xlib
+
+
+def check(rc: int, what: str = "", handle=None):
     if rc != SV_OK:
-        msg = lib().sv_last_error().decode("utf-8", "replace")
+        msg = (handle or lib()).sv_last_error().decode("utf-8", "replace")
         raise NativeError(f"{what or 'libsudokuvision_hip'}: {ERR_NAMES.get(rc, rc)}: {msg}")

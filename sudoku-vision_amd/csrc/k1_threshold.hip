@@ -13,7 +13,6 @@
 #include "sv_device.h"
 #include "sv_internal.h"
 #include "k2_cells_body.h"
-#include <cstdlib>
 
 namespace {
 
@@ -561,10 +560,6 @@ __global__ void k_adaptive_threshold(const u8 *__restrict__ src, int H, int W, F
 
 }  // namespace
 
-// SV_K1_ALGO: 0 (default) = the marching kernel, 1 = the matrix-pipe form (k1_threshold_mm.hip; same output, slower) where its layout
-// requirements hold
-static int k1_algo() { static const int a = [] { const char *e = getenv("SV_K1_ALGO"); return e ? atoi(e) : 0; }(); return a; }
-
 static RowPairs row_pairs(const Taps11 &t)
 {
     RowPairs rp;
@@ -587,8 +582,6 @@ int svk_preprocess_bits(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff
 {
     if (H < 16 || W < 16 || (W & 31) || (pitch % 4) || (img_stride % 4) || ((uintptr_t)bgr % 4))
         return sv_fail(SV_ERR_UNSUPPORTED, "sv_preprocess_bits_u8: needs H, W >= 16, W %% 32 == 0 and a 4-byte aligned frame layout");
-    if (k1_algo() == 1 && svk_preprocess_mm_supported(bgr, H, W, pitch, img_stride, bits, true))
-        return svk_preprocess_mm(ctx, bgr, n, H, W, pitch, img_stride, (u8 *)bits, true, nullptr, s);
     Taps11 t;
     sv_gaussian_taps_f32(11, t.k);
     sv_time_scope ts(ctx, SVK_PREPROCESS, s);
@@ -619,8 +612,6 @@ int svk_preprocess_warp_fused(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, p
 
 int svk_preprocess(sv_ctx *ctx, const u8 *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, u8 *binary, hipStream_t s)
 {
-    if (k1_algo() == 1 && svk_preprocess_mm_supported(bgr, H, W, pitch, img_stride, binary, false))
-        return svk_preprocess_mm(ctx, bgr, n, H, W, pitch, img_stride, binary, false, nullptr, s);
     Taps11 t;
     sv_gaussian_taps_f32(11, t.k);
     sv_time_scope ts(ctx, SVK_PREPROCESS, s);

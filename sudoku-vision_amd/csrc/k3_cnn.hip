@@ -1,9 +1,10 @@
-// K3 -- DigitCNN.forward (ml/model.py:34-42, eval mode) on MI355X, fp32 throughout.
+// K3 -- DigitCNN.forward (ml/model.py:34-42, eval mode) on MI355X: the f32-MFMA kernels and the small stages around the CNN.
+// (The default conv/fc pair -- f32-grade arithmetic on the f16 matrix pipe -- is k3_cnn_h2.hip; svk_cnn_forward at the end of this file
+// picks between the two, see sv_ctx_set_cnn_kernels.)
 //
-//   k_conv_features_wstream : the default conv kernel (Winograd, see its header below).
-//   k_conv_features_pc : the direct form, kept as an independent cross-check (SV_CONV_ALGO=0): persistent, one
-//        512-thread workgroup per CU working through PAIRS of cells.
-//        conv1 (1->32, 3x3, pad 1) + ReLU + 2x2 max-pool on the VALU into zero-bordered 16x16
+//   k_conv_features_pc : true f32 throughout, the reference's own numeric range: what runs when the loaded weights or an f32 input
+//        leave the range the f16-pair kernels carry exactly (and for misaligned 8-bit buffers).  Persistent, one 512-thread workgroup per
+//        CU working through PAIRS of cells.  conv1 (1->32, 3x3, pad 1) + ReLU + 2x2 max-pool on the VALU into zero-bordered 16x16
 //        planes in LDS; conv2 (32->64) as an implicit GEMM on v_mfma_f32_16x16x4_f32:
 //        M = 4 pooling windows x 4 positions, N = 16 output channels, K = 4 input channels of one
 //        3x3 tap per instruction.  A comes straight from the LDS planes (one ds_read_b32 with an
@@ -11,16 +12,16 @@
 //        144 VGPRs for the life of the kernel.  The 16x16 accumulator holds the 4 positions of a
 //        pooling window in the 4 registers of one lane, so bias + ReLU + max-pool are 3 v_max and
 //        never leave the lane.  Output: features [cell][window 49][oc 64] f32.
-//   k_fc_head_frame : fc1 (3136->128) on the same MFMA with cells as M, one workgroup per 81 cells, weights staged
-//        through double-buffered LDS; + ReLU, fc2 (128->10), argmax (pipeline/run.py:142) and softmax[argmax]
-//        (run.py:141-143).  k_fc_head: the same for small batches (16 cells per wave, weights streamed per wave).
+//   k_fc_head : fc1 (3136->128) on the same MFMA with cells as M (16 cells per wave, weights streamed per wave) + ReLU, fc2 (128->10),
+//        argmax (pipeline/run.py:142) and softmax[argmax] (run.py:141-143).
 //   k_softmax_topk, k_preprocess_cells: the run_v2 top-k epilogue and run.py's preprocess_cell (scope rows N3, N1).
+//   Under SV_XCHECK (libsudokuvision_xcheck.so, test-only): k_conv_features_wstream / _wsplit (round 1's Winograd stream on f32 and on
+//        split-bf16 MFMA) and k_fc_head_frame -- independent implementations the tests compare the product with.
 //
 // Weight images are packed on the host by sv_load_weights_f32 (sv_api.cpp) into exactly the
 // per-lane register order the kernels load.
 #include "sv_device.h"
 #include "sv_internal.h"
-#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -156,8 +157,9 @@ template <bool U8IN>
 __global__ __launch_bounds__(512, 2) void k_conv_features_pc(const void *__restrict__ xin, long B,
                                                              const float *__restrict__ w1, const float *__restrict__ b1,
                                                              const float *__restrict__ w2reg, const float *__restrict__ b2,
-                                                             float *__restrict__ feat)
+                                                             float *__restrict__ feat, const int *__restrict__ run_if_set)
 {
+    if (run_if_set && *run_if_set == 0) return;      // (svk_cnn_forward: the f16-pair kernels took this batch)
     __shared__ __attribute__((aligned(16))) float lds[4 * IN_CELL + 4 * C1_CELL];
     float *in_base = lds;                 // [2 buffers][2 cells][900]
     float *c1_base = lds + 4 * IN_CELL;   // [2 buffers][2 cells][32][257]
@@ -281,8 +283,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_pc(const void *__restr
     }
 }
 
+#ifdef SV_XCHECK   // cross-check kernels: built into libsudokuvision_xcheck.so only (csrc/Makefile), never into the product
 // ---------------------------------------------------------------------------------------------------
-// k_conv_features_wstream (the default): conv2 by Winograd F(2x2, 3x3), streamed.  The 7x7 grid of 2x2 output tiles of
+// k_conv_features_wstream (round 1's default; now a cross-check): conv2 by Winograd F(2x2, 3x3), streamed.  The 7x7 grid of 2x2 output tiles of
 // the 14x14 map IS the grid of pooling windows, so per tile:  V = B^T d B over 32 input channels (VALU, 32 add/sub),
 // 16 independent GEMMs  M[xi] = V[xi] (tiles x 32) * U[xi] (32 x 64)  on v_mfma_f32_16x16x4_f32, and
 // Y = A^T M A + bias, ReLU, 2x2 max -- all four outputs of a tile live in the lane that owns (tile, channel), because
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wstream(const void *__
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_conv_features_wsplit (experimental, SV_CONV_ALGO=3; measured 0.83 ms against the default's 0.81 ms): the Winograd stream
+// k_conv_features_wsplit (experimental, SV_CNN_X_WSPLIT; measured 0.83 ms against the default's 0.81 ms): the Winograd stream
 // with its 16 GEMMs on the bf16 matrix pipe at f32 accuracy.
 // On gfx950 an f32 MFMA runs at the VALU's rate and blocks the SIMD's VALU issue while it runs (profiles/
 // r01_ubench_mfma_valu_coexec.txt); v_mfma_f32_16x16x32_bf16 does 8x the work per cycle and co-issues with VALU work.  Each
@@ -747,12 +750,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_wsplit(const void *__r
     if (xh == 0) finish(NM - 1);
 }
 
+#endif  // SV_XCHECK
+
 // 64 cells per workgroup, 16 per wave; K = 3136 in 196 chunks of 16.
 __global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat, long B, const float *__restrict__ w1reg,
                                                  const float *__restrict__ b1, const float *__restrict__ w2,
                                                  const float *__restrict__ b2, float *__restrict__ logits,
-                                                 u8 *__restrict__ digits, float *__restrict__ conf)
+                                                 u8 *__restrict__ digits, float *__restrict__ conf, const int *__restrict__ run_if_set)
 {
+    if (run_if_set && *run_if_set == 0) return;
     __shared__ float hs[4][16][129];
     __shared__ float w2s[10][128];
     __shared__ float lg[4][16][12];
@@ -831,6 +837,7 @@ __global__ __launch_bounds__(256) void k_fc_head(const float *__restrict__ feat,
     }
 }
 
+#ifdef SV_XCHECK
 // ---------------------------------------------------------------------------------------------------
 // k_fc_head_frame: one 512-thread workgroup per 81 cells (one frame), i.e. one per CU at 256 frames, so the MFMA work is
 // spread evenly, and the fc1 weight image is fetched ONCE per workgroup: each 32-wide K stage (16 KB) goes global ->
@@ -949,6 +956,8 @@ __global__ __launch_bounds__(512) void k_fc_head_frame(const float *__restrict__
     }
 }
 
+#endif  // SV_XCHECK
+
 // preprocess_cell (pipeline/run.py:73-95) as a stand-alone call: one wave per cell, u8 in -> u8 {0,255} out
 __global__ __launch_bounds__(256) void k_preprocess_cells(const u8 *__restrict__ cells, long B, GaussTaps taps, u8 *__restrict__ out)
 {
@@ -1008,22 +1017,54 @@ int svk_softmax_topk(const float *logits, long B, int k, u8 *index, float *prob,
     return SV_OK;
 }
 
-// which conv/fc kernels run: 4 = f16 hi/lo operand pairs on the f16 matrix pipe (k3_cnn_h2.hip, default); the f32-MFMA forms stay
-// selectable as cross-checks: 2 = Winograd stream, 0 = direct implicit GEMM (k_conv_features_pc); 3 = Winograd stream on bf16 MFMA
-// with three-way operand splitting (k_conv_features_wsplit)
-static int conv_algo_env()
+// Which conv/fc kernels run (sv_ctx_set_cnn_kernels; include/sudoku_vision_hip.h):
+//   SV_CNN_AUTO (default)  the f16 hi/lo operand-pair kernels (k3_cnn_h2.hip) whenever the loaded weights keep every activation inside their
+//                          range, else the f32-MFMA kernels below, which have the reference's own range (sv_load_weights_f32 decides; f32
+//                          inputs are range-checked on the device per call)
+//   SV_CNN_F16PAIR / SV_CNN_F32MFMA   one of the two, unconditionally
+//   (libsudokuvision_xcheck.so only) SV_CNN_X_WINOGRAD, SV_CNN_X_WSPLIT: the round-1 Winograd stream on f32 / on split-bf16 MFMA, and
+//   SV_FC_X_FRAME for the one-workgroup-per-frame fc kernel -- independent implementations the tests compare the product with
+static int effective_algo(const sv_ctx *ctx)
 {
-    static const int algo = getenv("SV_CONV_ALGO") ? atoi(getenv("SV_CONV_ALGO")) : 4;
-    return algo;
+    switch (ctx->cnn_kernels) {
+    case SV_CNN_F16PAIR: return 4;
+    case SV_CNN_F32MFMA: return 0;
+#ifdef SV_XCHECK
+    case SV_CNN_X_WINOGRAD: return 2;
+    case SV_CNN_X_WSPLIT: return 3;
+#endif
+    default: return ctx->w.h2_in_range ? 4 : 0;
+    }
 }
+
+extern "C" int sv_ctx_set_cnn_kernels(sv_ctx *ctx, int which)
+{
+    if (!ctx) return sv_fail(SV_ERR_BAD_ARG, "sv_ctx_set_cnn_kernels: NULL context");
+    bool ok = which == SV_CNN_AUTO || which == SV_CNN_F16PAIR || which == SV_CNN_F32MFMA;
+#ifdef SV_XCHECK
+    ok = ok || which == SV_CNN_X_WINOGRAD || which == SV_CNN_X_WSPLIT;
+#endif
+    if (!ok) return sv_fail(SV_ERR_BAD_ARG, "sv_ctx_set_cnn_kernels: unknown selection %d", which);
+    ctx->cnn_kernels = which;
+    return SV_OK;
+}
+
+#ifdef SV_XCHECK
+extern "C" int svx_ctx_set_fc_frame_kernel(sv_ctx *ctx, int on)
+{
+    if (!ctx) return sv_fail(SV_ERR_BAD_ARG, "svx_ctx_set_fc_frame_kernel: NULL context");
+    ctx->x_fc_frame = on != 0;
+    return SV_OK;
+}
+#endif
 
 extern "C" int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_f32_conv2_per_cell, int *mfma_f32_conv1_per_cell, int *mfma_f16_conv_per_cell,
                                    int *mfma_f16_fc_per_cell)
 {
     if (!ctx || !algo || !mfma_f32_conv2_per_cell || !mfma_f32_conv1_per_cell || !mfma_f16_conv_per_cell || !mfma_f16_fc_per_cell)
         return sv_fail(SV_ERR_BAD_ARG, "sv_conv_kernel_info: NULL argument");
-    const int a = conv_algo_env();
-    *algo = (a == 2 || a == 3 || a == 4) ? a : 0;
+    const int a = effective_algo(ctx);
+    *algo = a;
     // f32 Winograd: 49 tiles x 16 xi x 8 k-steps x 4 N tiles / 16 tiles per M tile; f32 direct: 196 positions / 16 x 72 k-steps x 4 N tiles
     *mfma_f32_conv2_per_cell = a == 2 ? 1568 : ((a == 3 || a == 4) ? 0 : 3600);
     *mfma_f32_conv1_per_cell = 0;
@@ -1031,6 +1072,33 @@ extern "C" int sv_conv_kernel_info(sv_ctx *ctx, int *algo, int *mfma_f32_conv2_p
     *mfma_f16_conv_per_cell = a == 4 ? 13 * 9 * 4 * 3 + 13 * 8 * 2 : 0;
     *mfma_f16_fc_per_cell = a == 4 ? 98 * 8 * 3 / 16 : 0;
     return SV_OK;
+}
+
+// |x| of an f32 input batch against the range the f16-pair kernels carry exactly: flag = 0 (use them) when lo <= max|x| <= hi and no
+// value is NaN/Inf, else 1 (the f32-MFMA kernels).  One pass over the input; both kernel pairs are launched and the one the flag does
+// not name returns at once, so the decision never costs a host synchronisation.
+__global__ __launch_bounds__(256) void k_input_range(const float *__restrict__ x, long n, float lo, float hi, int *__restrict__ flag)
+{
+    __shared__ float part[4];
+    float m = 0.f;
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = fabsf(x[i]);
+        bad |= !(v <= hi);                                          // also NaN
+        m = fmaxf(m, v);
+    }
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        if (m >= lo) atomicOr(flag + 1, 1);                         // some block saw a value of at least lo
+    }
+}
+__global__ void k_input_range_finish(int *flag)                     // flag[0] |= nothing reached lo (all-tiny input); flag[1] is scratch
+{
+    if (flag[1] == 0) flag[0] = 1;
 }
 
 int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
@@ -1042,42 +1110,59 @@ int svk_cnn_forward(sv_ctx *ctx, const void *x, bool x_is_u8, int glue, long B, 
         if (rc) return rc;
         x = ctx->cells2;
     }
-    const int conv_algo = conv_algo_env();
+    int conv_algo = effective_algo(ctx);
     // (the kernels that read 8-bit cells as dwords need a 4-byte-aligned buffer; a misaligned one takes the direct f32 kernel)
-    if (conv_algo == 4 && !(x_is_u8 && ((uintptr_t)x & 3))) return svk_cnn_forward_h2(ctx, x, x_is_u8, B, logits, digits, conf, s);
-    if (conv_algo == 3 && ((uintptr_t)x & 3) == 0) {
+    if (x_is_u8 && ((uintptr_t)x & 3)) conv_algo = 0;
+    const int *flag = nullptr;                   // device flag: 0 = the f16-pair kernels run, 1 = the f32-MFMA kernels (both are launched)
+    if (conv_algo == 4 && !x_is_u8 && ctx->cnn_kernels == SV_CNN_AUTO) {
+        // 8-bit cells are in [-1, 1] after the glue (what sv_load_weights_f32 sized the activations for); f32 input can be anything
+        if (!ctx->range_flag) SV_HIP(hipMalloc((void **)&ctx->range_flag, 2 * sizeof(int)));
+        SV_HIP(hipMemsetAsync(ctx->range_flag, 0, 2 * sizeof(int), s));
+        const long n = B * 784;
+        hipLaunchKernelGGL(k_input_range, dim3((unsigned)(n / 4096 + 1 < 1024 ? n / 4096 + 1 : 1024)), dim3(256), 0, s, (const float *)x, n, w.h2_x_lo, w.h2_x_hi, ctx->range_flag);
+        hipLaunchKernelGGL(k_input_range_finish, dim3(1), dim3(1), 0, s, ctx->range_flag);
+        SV_LAUNCH_CHECK("k_input_range");
+        flag = ctx->range_flag;
+    }
+    if (conv_algo == 4) {
+        const int rc = svk_cnn_forward_h2(ctx, x, x_is_u8, B, logits, digits, conf, flag, s);
+        if (rc || !flag) return rc;
+    }
+#ifdef SV_XCHECK
+    if (conv_algo == 3 || conv_algo == 2) {
         long cpw = (B + ctx->num_cus - 1) / ctx->num_cus;
         if (cpw < 1) cpw = 1;
         const int grid_s = (int)((B + cpw - 1) / cpw);
         sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
-        if (x_is_u8)
-            hipLaunchKernelGGL(k_conv_features_wsplit<true>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, (const uint4 *)w.conv2_wsplit, w.conv2_b, ctx->features);
-        else
-            hipLaunchKernelGGL(k_conv_features_wsplit<false>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, (const uint4 *)w.conv2_wsplit, w.conv2_b, ctx->features);
-    } else if (conv_algo == 2 && ((uintptr_t)x & 3) == 0) {             // the stream kernel reads 8-bit cells as dwords; a misaligned buffer takes the direct kernel
-        long cpw = (B + ctx->num_cus - 1) / ctx->num_cus;
-        if (cpw < 1) cpw = 1;
-        const int grid_s = (int)((B + cpw - 1) / cpw);
-        sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
-        if (x_is_u8)
-            hipLaunchKernelGGL(k_conv_features_wstream<true>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, w.conv2_wino, w.conv2_b, ctx->features);
-        else
-            hipLaunchKernelGGL(k_conv_features_wstream<false>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, w.conv2_wino, w.conv2_b, ctx->features);
-    } else {
+        if (conv_algo == 3) {
+            if (x_is_u8)
+                hipLaunchKernelGGL(k_conv_features_wsplit<true>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, (const uint4 *)w.conv2_wsplit, w.conv2_b, ctx->features);
+            else
+                hipLaunchKernelGGL(k_conv_features_wsplit<false>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, (const uint4 *)w.conv2_wsplit, w.conv2_b, ctx->features);
+        } else {
+            if (x_is_u8)
+                hipLaunchKernelGGL(k_conv_features_wstream<true>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, w.conv2_wino, w.conv2_b, ctx->features);
+            else
+                hipLaunchKernelGGL(k_conv_features_wstream<false>, dim3(grid_s), dim3(512), 0, s, x, B, cpw, w.conv1_w, w.conv1_b, w.conv2_wino, w.conv2_b, ctx->features);
+        }
+    } else
+#endif
+    {
         const int grid_pc = (int)(npairs < (long)ctx->num_cus ? npairs : (long)ctx->num_cus);
         sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
         if (x_is_u8)
-            hipLaunchKernelGGL(k_conv_features_pc<true>, dim3(grid_pc), dim3(512), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
+            hipLaunchKernelGGL(k_conv_features_pc<true>, dim3(grid_pc), dim3(512), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features, flag);
         else
-            hipLaunchKernelGGL(k_conv_features_pc<false>, dim3(grid_pc), dim3(512), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features);
+            hipLaunchKernelGGL(k_conv_features_pc<false>, dim3(grid_pc), dim3(512), 0, s, x, B, w.conv1_w, w.conv1_b, w.conv2_wreg, w.conv2_b, ctx->features, flag);
     }
     SV_LAUNCH_CHECK("k_conv_features");
     sv_time_scope ts(ctx, SVK_FC_HEAD, s);
-    static const int fc_algo = getenv("SV_FC_ALGO") ? atoi(getenv("SV_FC_ALGO")) : 1;   // tuning aid
-    if (fc_algo == 1 && B >= 81 * 64)        // enough frames to give most CUs a workgroup
+#ifdef SV_XCHECK
+    if (ctx->x_fc_frame && B >= 81 * 64)       // enough frames to give most CUs a workgroup
         hipLaunchKernelGGL(k_fc_head_frame, dim3((unsigned)((B + 80) / 81)), dim3(512), 0, s, ctx->features, B, w.fc1_wreg, w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
     else
-    hipLaunchKernelGGL(k_fc_head, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, ctx->features, B, w.fc1_wreg, w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
+#endif
+    hipLaunchKernelGGL(k_fc_head, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, ctx->features, B, w.fc1_wreg, w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf, flag);
     SV_LAUNCH_CHECK("k_fc_head");
     return SV_OK;
 }

@@ -23,10 +23,13 @@
 //        image (hi and lo halves) is staged once per workgroup through double-buffered LDS, features are read as f32 from
 //        global memory and split in registers; fc2 + argmax + softmax[argmax] epilogue in f32 (pipeline/run.py:139-143).
 //
-// The pure f32-MFMA kernels (k3_cnn.hip) remain selectable (SV_CONV_ALGO=2 / 0) and are what tests compare this file with.
+// Range: inputs and activations are carried as f16 pairs, so their magnitudes must stay below 65,504 (and a pair holds 22 significant bits
+// only while its low half is a normal f16; below that the absolute error is f16's subnormal step, 2^-24).  sv_load_weights_f32 bounds the
+// activations from the weights
+// and svk_cnn_forward (k3_cnn.hip) routes anything outside to the f32-MFMA kernels; `run_if_clear` is that decision for f32 inputs, made
+// on the device.  SV_DEV builds (tools/dev) add an ablation switch and s_memtime stamps; the product is compiled without them.
 #include "sv_device.h"
 #include "sv_internal.h"
-#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -78,8 +81,16 @@ __device__ __forceinline__ void split_h2(float v, _Float16 &hi, _Float16 &lo)
 template <bool U8IN>
 __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restrict__ xin, long B, const uint4 *__restrict__ w1img,
                                                              const float *__restrict__ b1, float scale1_inv, const uint4 *__restrict__ w2img,
-                                                             const float *__restrict__ b2, float scale_inv, float *__restrict__ feat, int ablate)
+                                                             const float *__restrict__ b2, float scale_inv, float *__restrict__ feat, const int *__restrict__ run_if_clear
+#ifdef SV_DEV
+                                                             , int ablate
+#endif
+                                                             )
 {
+#ifndef SV_DEV
+    constexpr int ablate = 0;
+#endif
+    if (run_if_clear && *run_if_clear != 0) return;          // (svk_cnn_forward: this batch is outside the f16-pair range; the f32-MFMA kernels take it)
     __shared__ __attribute__((aligned(16))) unsigned char c1[2][2 * PLANE_B];  // [cell parity][part hi/lo][position][32 ch f16 + pad]
     __shared__ __attribute__((aligned(16))) unsigned char inh[2][2][IN_PLANE_B]; // input [slot][part hi/lo][32 rows][32 f16], zero border
     __shared__ __attribute__((aligned(8))) unsigned short lut_in[208], lut_out[208];
@@ -356,8 +367,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
 __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__ feat, long B, const uint4 *__restrict__ w1img,
                                                        const float *__restrict__ b1, float scale_inv, const float *__restrict__ w2,
                                                        const float *__restrict__ b2, float *__restrict__ logits,
-                                                       u8 *__restrict__ digits, float *__restrict__ conf)
+                                                       u8 *__restrict__ digits, float *__restrict__ conf, const int *__restrict__ run_if_clear)
 {
+    if (run_if_clear && *run_if_clear != 0) return;
     constexpr int SPS = 2, STAGE_V = SPS * 8 * 2 * 64, NSTAGE = 98 / SPS, WPT = STAGE_V / 256;   // uint4 per stage, per thread
     __shared__ __attribute__((aligned(16))) uint4 wt[2][STAGE_V];    // 2 x 32 KB; the hidden activations alias it after the K loop
     __shared__ float w2s[10][128];
@@ -460,26 +472,31 @@ __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__
 
 }  // namespace
 
-int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
+int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, const int *run_if_clear, hipStream_t s)
 {
     const sv_weights &w = ctx->w;
     const int grid = (int)(B < (long)ctx->num_cus ? B : (long)ctx->num_cus);
-    // tuning aid: SV_H2_ABLATE bit 0 skips the producers' conv1 tiles, bit 1 the consumers' conv2 tiles (wrong results); bit 4 makes
-    // the consumer waves of workgroups 0 and 1 print s_memtime stamps of their per-cell phases
-    static const int ablate = getenv("SV_H2_ABLATE") ? atoi(getenv("SV_H2_ABLATE")) : 0;
+#ifdef SV_DEV
+    // development builds only: ctx->dev_ablate bit 0 skips the producers' conv1 tiles, bit 1 the consumers' conv2 tiles (wrong results); bit 4
+    // makes the consumer waves of workgroups 0 and 1 print s_memtime stamps of their per-cell phases
+#define SV_ABLATE_ARG , ctx->dev_ablate
+#else
+#define SV_ABLATE_ARG
+#endif
     {
         sv_time_scope ts(ctx, SVK_CONV_FEATURES, s);
         if (x_is_u8)
             hipLaunchKernelGGL(k_conv_features_h2<true>, dim3(grid), dim3(512), 0, s, x, B, (const uint4 *)w.conv1_h2, w.conv1_b, w.conv1_h2_scale_inv, (const uint4 *)w.conv2_h2, w.conv2_b,
-                               w.conv2_h2_scale_inv, ctx->features, ablate);
+                               w.conv2_h2_scale_inv, ctx->features, run_if_clear SV_ABLATE_ARG);
         else
             hipLaunchKernelGGL(k_conv_features_h2<false>, dim3(grid), dim3(512), 0, s, x, B, (const uint4 *)w.conv1_h2, w.conv1_b, w.conv1_h2_scale_inv, (const uint4 *)w.conv2_h2, w.conv2_b,
-                               w.conv2_h2_scale_inv, ctx->features, ablate);
+                               w.conv2_h2_scale_inv, ctx->features, run_if_clear SV_ABLATE_ARG);
     }
+#undef SV_ABLATE_ARG
     SV_LAUNCH_CHECK("k_conv_features_h2");
     sv_time_scope ts(ctx, SVK_FC_HEAD, s);
     hipLaunchKernelGGL(k_fc_head_h2, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, ctx->features, B, (const uint4 *)w.fc1_h2, w.fc1_b, w.fc1_h2_scale_inv,
-                       w.fc2_w, w.fc2_b, logits, digits, conf);
+                       w.fc2_w, w.fc2_b, logits, digits, conf, run_if_clear);
     SV_LAUNCH_CHECK("k_fc_head_h2");
     return SV_OK;
 }

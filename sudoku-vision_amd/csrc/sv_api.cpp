@@ -20,7 +20,7 @@ int sv_fail(int code, const char *fmt, ...)
 }
 
 extern "C" const char *sv_last_error(void) { return g_err; }
-extern "C" int sv_version(void) { return 1; }
+extern "C" int sv_version(void) { return 2; }
 
 // ---- context --------------------------------------------------------------------------------------
 extern "C" int sv_ctx_create(int device, sv_ctx **out)
@@ -69,6 +69,7 @@ extern "C" int sv_ctx_destroy(sv_ctx *ctx)
     if (ctx->cells2) (void)hipFree(ctx->cells2);
     if (ctx->jpeg_planes) (void)hipFree(ctx->jpeg_planes);
     if (ctx->k1_list) (void)hipFree(ctx->k1_list);
+    if (ctx->range_flag) (void)hipFree(ctx->range_flag);
     for (auto &t : ctx->timeline) { (void)hipEventDestroy(t.t0); (void)hipEventDestroy(t.t1); }
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -134,17 +135,19 @@ extern "C" int sv_timing_begin(sv_ctx *ctx)
     return SV_OK;
 }
 
-extern "C" int sv_timing_end(sv_ctx *ctx, double *ms_total, long *launches)
+extern "C" int sv_timing_end(sv_ctx *ctx, double *ms_total, long *launches, int n_kernels)
 {
-    if (!ctx || !ms_total || !launches) return sv_fail(SV_ERR_BAD_ARG, "sv_timing_end: NULL argument");
+    if (!ctx || !ms_total || !launches || n_kernels < 0) return sv_fail(SV_ERR_BAD_ARG, "sv_timing_end: bad argument");
     ctx->timing = false;
-    for (int k = 0; k < SVK_COUNT; k++) { ms_total[k] = 0; launches[k] = 0; }
+    for (int k = 0; k < n_kernels; k++) { ms_total[k] = 0; launches[k] = 0; }
     for (auto &t : ctx->timeline) {
         SV_HIP(hipEventSynchronize(t.t1));
         float ms = 0;
         SV_HIP(hipEventElapsedTime(&ms, t.t0, t.t1));
-        ms_total[t.kernel] += ms;
-        launches[t.kernel]++;
+        if (t.kernel < n_kernels) {                   // a caller built against an older header simply does not see the newer kernel ids
+            ms_total[t.kernel] += ms;
+            launches[t.kernel]++;
+        }
         ctx->event_pool.push_back(t.t0);
         ctx->event_pool.push_back(t.t1);
     }
@@ -186,6 +189,7 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
                     const int kp = 16 * c + 4 * (lane >> 4) + e, win = kp >> 6, oc = kp & 63, n = 16 * t + (lane & 15);
                     f1[(((size_t)c * 8 + t) * 64 + lane) * 4 + e] = f1w[(size_t)n * 3136 + oc * 49 + win];
                 }
+#ifdef SV_XCHECK
     // Winograd F(2x2,3x3) weights U = G g G^T (computed in double), as [nt][xi][ks][lane]: oc = 16nt + (lane&15), ic = 4ks + (lane>>4)
     std::vector<float> wino((size_t)4 * 16 * 8 * 64);
     // the same U split without error into three bf16 parts (each the next 8 mantissa bits, by truncation) for
@@ -218,6 +222,7 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
                 }
             }
     }
+#endif
     // bf16 configuration: round-to-nearest-even images for v_mfma_f32_16x16x32_bf16.
     //   conv2 [tap][t][lane][j]: oc = 4*(lane&15) + t, ic = 8*(lane>>4) + j
     //   fc1   [step][t][lane][j]: n = 16t + (lane&15), feature k' = 32*step + 8*(lane>>4) + j = window*64 + oc
@@ -300,8 +305,11 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
     SV_HIP(hipMemcpy(ctx->w.conv2_h2, c2h.data(), c2h.size() * 2, hipMemcpyHostToDevice));
     SV_HIP(hipMalloc((void **)&ctx->w.fc1_h2, f1h.size() * 2));
     SV_HIP(hipMemcpy(ctx->w.fc1_h2, f1h.data(), f1h.size() * 2, hipMemcpyHostToDevice));
+#ifdef SV_XCHECK
     SV_HIP(hipMalloc((void **)&ctx->w.conv2_wsplit, wsplit.size() * 2));
     SV_HIP(hipMemcpy(ctx->w.conv2_wsplit, wsplit.data(), wsplit.size() * 2, hipMemcpyHostToDevice));
+    if (int rcx = upload(&ctx->w.conv2_wino, wino)) return rcx;
+#endif
     SV_HIP(hipMalloc((void **)&ctx->w.conv2_bf16, w2b.size() * 2));
     SV_HIP(hipMemcpy(ctx->w.conv2_bf16, w2b.data(), w2b.size() * 2, hipMemcpyHostToDevice));
     SV_HIP(hipMalloc((void **)&ctx->w.fc1_bf16, fc1b.size() * 2));
@@ -310,12 +318,30 @@ extern "C" int sv_load_weights_f32(sv_ctx *ctx, const float *blob)
     if ((rc = upload(&ctx->w.conv1_w, std::vector<float>(c1w, c1w + 288)))) return rc;
     if ((rc = upload(&ctx->w.conv1_b, std::vector<float>(c1b, c1b + 32)))) return rc;
     if ((rc = upload(&ctx->w.conv2_wreg, w2))) return rc;
-    if ((rc = upload(&ctx->w.conv2_wino, wino))) return rc;
     if ((rc = upload(&ctx->w.conv2_b, std::vector<float>(c2b, c2b + 64)))) return rc;
     if ((rc = upload(&ctx->w.fc1_wreg, f1))) return rc;
     if ((rc = upload(&ctx->w.fc1_b, std::vector<float>(f1b, f1b + 128)))) return rc;
     if ((rc = upload(&ctx->w.fc2_w, std::vector<float>(f2w, f2w + 1280)))) return rc;
     if ((rc = upload(&ctx->w.fc2_b, std::vector<float>(f2b, f2b + 10)))) return rc;
+    // Range of the f16-pair kernels for these weights (k3_cnn_h2.hip carries inputs, conv1 activations and features as f16 pairs: each
+    // must stay below f16's 65,504).  Worst case over inputs of magnitude <= xm:  |conv1| <= A1*xm + B1,  |features| <= A2*(A1*xm + B1) + B2
+    // with A = the largest absolute row sum of a layer's weights, B = its largest |bias|.  h2_x_hi = the largest xm all three bounds allow;
+    // 8-bit cells are in [-1, 1] after the glue, so the f16-pair kernels serve them iff h2_x_hi >= 1.  Below 2^-10 an input's low halves
+    // are all f16-subnormal; such batches take the f32 kernels too.
+    {
+        auto row_sum_max = [](const float *wt, int rows, int cols) { double m = 0; for (int r = 0; r < rows; r++) { double a = 0; for (int c = 0; c < cols; c++) a += std::fabs((double)wt[(size_t)r * cols + c]); m = std::fmax(m, a); } return m; };
+        auto abs_max = [](const float *v, int n) { double m = 0; for (int i = 0; i < n; i++) m = std::fmax(m, std::fabs((double)v[i])); return m; };
+        const double LIM = 6.0e4, A1 = row_sum_max(c1w, 32, 9), B1 = abs_max(c1b, 32), A2 = row_sum_max(c2w, 64, 288), B2 = abs_max(c2b, 64);
+        double hi = LIM;
+        if (A1 > 0) hi = std::fmin(hi, (LIM - B1) / A1);
+        else if (B1 > LIM) hi = -1;
+        if (A2 > 0 && A1 > 0) hi = std::fmin(hi, ((LIM - B2) / A2 - B1) / A1);
+        else if (A2 * B1 + B2 > LIM) hi = -1;
+        if (!std::isfinite(A1) || !std::isfinite(A2) || !std::isfinite(B1) || !std::isfinite(B2) || !(hi == hi)) hi = -1;
+        ctx->w.h2_x_hi = (float)hi;
+        ctx->w.h2_x_lo = 0x1p-10f;
+        ctx->w.h2_in_range = hi >= 1.0;
+    }
     ctx->w.loaded = true;
     return SV_OK;
 }
@@ -506,6 +532,7 @@ extern "C" int sv_preprocess_warp_cells_u8(sv_ctx *ctx, const uint8_t *bgr, int 
     return svk_preprocess_warp_fused(ctx, bgr, n, H, W, pitch, img_stride, binary, minv, cells, S(stream));
 }
 
+#ifdef SV_XCHECK   // the matrix-pipe formulation of K1: a second implementation, built into the test-only library
 extern "C" int sv_preprocess_mm_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint8_t *binary, float *mean, void *stream)
 {
     REQUIRE(ctx && bgr && binary, "NULL argument");
@@ -521,6 +548,8 @@ extern "C" int sv_preprocess_stats(sv_ctx *ctx, unsigned *ambiguous, unsigned lo
     if (!ctx->k1_list) { *ambiguous = 0; *capacity = 0; return svk_preprocess_mm_enable_stats(ctx); }
     return svk_preprocess_mm_stats(ctx, ambiguous, capacity);
 }
+
+#endif  // SV_XCHECK
 
 extern "C" int sv_preprocess_bits_u8(sv_ctx *ctx, const uint8_t *bgr, int n, int H, int W, ptrdiff_t pitch, ptrdiff_t img_stride, uint32_t *bits, void *stream)
 {

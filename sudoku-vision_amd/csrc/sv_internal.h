@@ -7,6 +7,9 @@
 #include <vector>
 
 #include "../../include/sudoku_vision_hip.h"
+#ifdef SV_XCHECK
+#include "../../include/sudoku_vision_xcheck.h"
+#endif
 
 typedef uint8_t u8;
 
@@ -27,6 +30,10 @@ struct sv_weights {
     unsigned short *fc1_h2 = nullptr;     // [98 step][8 t][2 part][64 lane][8] f16: n = 16t + (lane&15), feature = 64*(step/2) + 16*(lane>>4) + 8*(step%2) + j
     unsigned short *conv1_h2 = nullptr;   // [2 chalf][4 pos][2 mfma][64 lane][8] f16: conv1 as a GEMM over the 4x4 patch of a pooling window (k3_cnn_h2.hip)
     float conv1_h2_scale_inv = 1.f, conv2_h2_scale_inv = 1.f, fc1_h2_scale_inv = 1.f;
+    // range of the f16-pair kernels for THESE weights (sv_load_weights_f32): with inputs in [-1, 1] (8-bit cells after the glue) every activation
+    // stays below the f16 range iff h2_in_range; an f32 input batch is inside it iff h2_x_lo <= max|x| <= h2_x_hi (0 > hi: never)
+    bool h2_in_range = true;
+    float h2_x_lo = 0.f, h2_x_hi = 0.f;
     float *fc2_w = nullptr;     // [10][128]
     float *fc2_b = nullptr;     // [10]
     bool loaded = false;
@@ -45,6 +52,10 @@ struct sv_ctx {
     size_t cap_jpeg = 0;
     void *k1_list = nullptr;    // k1_threshold_mm.hip: optional diagnostic counter (pixels decided by the exact evaluation), sv_preprocess_stats
     int precision = 0;          // SV_PREC_F32 / SV_PREC_BF16 (sv_ctx_set_precision)
+    int cnn_kernels = 0;        // SV_CNN_AUTO / _F16PAIR / _F32MFMA (sv_ctx_set_cnn_kernels)
+    int *range_flag = nullptr;  // [2] device ints: the per-call kernel choice for f32 inputs (k3_cnn.hip k_input_range)
+    bool x_fc_frame = false;    // xcheck builds: k_fc_head_frame for large batches
+    int dev_ablate = 0;         // SV_DEV builds: k3_cnn_h2.hip ablation / stamp bits
     // optional per-kernel timing (sv_timing_begin/sv_timing_end): hipEvents on the launch stream
     bool timing = false;
     struct timed { int kernel; hipEvent_t t0, t1; };
@@ -105,7 +116,7 @@ int svk_pack_sparse_bits(const uint32_t *bits, int n, int H, int W, u8 *records,
 int svk_copy_to_host(const void *src, void *dst_host, size_t bytes, hipStream_t s);
 int svk_resize_linear(const u8 *src, int sh, int sw, ptrdiff_t pitch, u8 *dst, int dh, int dw, hipStream_t s);
 int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8 *digits, float *conf, hipStream_t s);
-int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, hipStream_t s);
+int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, const int *run_if_clear, hipStream_t s);
 int svk_cell_ink_ratio(const u8 *cells, long B, int npx, float *ratio, int *otsu, hipStream_t s);
 int svk_preprocess_cells(const u8 *cells, long B, u8 *out, hipStream_t s);
 int svk_jpeg_reconstruct(sv_ctx *ctx, const sv_jpeg_info *info, const int16_t *coef, const uint64_t *masks, const uint32_t *offsets, const int16_t *values,

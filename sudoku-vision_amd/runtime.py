@@ -43,16 +43,28 @@ def _frame_layout(frames):
 
 
 class Context:
-    def __init__(self, device=None):
+    def __init__(self, device=None, library=None):
+        """library: a handle from _native (default: the product library).  Tests pass _native.lib_xcheck() to run the cross-check kernels of
+        the test-only build through the same methods."""
         _require_gpu()
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        self._lib = library or _native.lib()
         self._h = C.c_void_p()
-        _native.check(_native.lib().sv_ctx_create(self.device.index, C.byref(self._h)), "sv_ctx_create")
+        self._check(self._lib.sv_ctx_create(self.device.index, C.byref(self._h)), "sv_ctx_create")
         self._weights_key = None
+
+    def _check(self, rc, what):
+        _native.check(rc, what, self._lib)
+
+    def _out(self, t, shape, dtype, name):
+        """A caller-provided output tensor: the kernels write shape-many elements through its raw pointer, so it has to be exactly that."""
+        if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != dtype or not t.is_contiguous() or t.device != self.device:
+            raise TypeError(f"{name} must be a contiguous {dtype} tensor of shape {list(shape)} on {self.device}")
+        return t
 
     def close(self):
         if self._h:
-            _native.lib().sv_ctx_destroy(self._h)
+            self._lib.sv_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -73,40 +85,48 @@ class Context:
             parts.append(np.ascontiguousarray(v).reshape(-1))
         blob = np.concatenate(parts)
         assert blob.size == 421642
-        _native.check(_native.lib().sv_load_weights_f32(self._h, blob.ctypes.data_as(C.c_void_p)), "sv_load_weights_f32")
+        self._check(self._lib.sv_load_weights_f32(self._h, blob.ctypes.data_as(C.c_void_p)), "sv_load_weights_f32")
         self._weights_key = key
 
     PREC_F32, PREC_BF16 = 0, 1
 
     def set_precision(self, precision):
         """PREC_F32 (default, logits within 1e-4 of the reference model) or PREC_BF16 (bf16 MFMA, digit-index parity)."""
-        _native.check(_native.lib().sv_ctx_set_precision(self._h, int(precision)), "sv_ctx_set_precision")
+        self._check(self._lib.sv_ctx_set_precision(self._h, int(precision)), "sv_ctx_set_precision")
+
+    CNN_AUTO, CNN_F16PAIR, CNN_F32MFMA = 0, 1, 2
+    CNN_X_WINOGRAD, CNN_X_WSPLIT = 102, 103          # cross-check selections of the test-only library (include/sudoku_vision_xcheck.h)
+
+    def set_cnn_kernels(self, which):
+        """CNN_AUTO (default: the f16-pair kernels whenever the weights / inputs are inside their range, else the f32-MFMA kernels),
+        CNN_F16PAIR or CNN_F32MFMA (sv_ctx_set_cnn_kernels)."""
+        self._check(self._lib.sv_ctx_set_cnn_kernels(self._h, int(which)), "sv_ctx_set_cnn_kernels")
 
     def reserve(self, max_cells):
-        _native.check(_native.lib().sv_ctx_reserve(self._h, int(max_cells)), "sv_ctx_reserve")
+        self._check(self._lib.sv_ctx_reserve(self._h, int(max_cells)), "sv_ctx_reserve")
 
     # ---- per-kernel timing (hipEvents on the launch stream, inside the library) -------------------
     KERNELS = ("k_preprocess", "k_warp_cells", "k_conv_features", "k_fc_head", "k_preprocess_warp_fused")
 
     def timing_begin(self):
-        _native.check(_native.lib().sv_timing_begin(self._h), "sv_timing_begin")
+        self._check(self._lib.sv_timing_begin(self._h), "sv_timing_begin")
 
     def timing_end(self):
         """-> {kernel name: (total ms, launches)}; waits for the recorded events."""
         ms = (C.c_double * len(self.KERNELS))()
         cnt = (C.c_long * len(self.KERNELS))()
-        _native.check(_native.lib().sv_timing_end(self._h, ms, cnt), "sv_timing_end")
+        self._check(self._lib.sv_timing_end(self._h, ms, cnt, len(self.KERNELS)), "sv_timing_end")
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNELS)}
 
-    CONV_ALGO_NAMES = {0: "k_conv_features_pc + k_fc_head_frame (direct implicit GEMM, f32 MFMA)",
-                       2: "k_conv_features_wstream + k_fc_head_frame (Winograd F(2x2,3x3), f32 MFMA)",
-                       3: "k_conv_features_wsplit + k_fc_head_frame (Winograd, bf16 MFMA with 3-way operand split)",
+    CONV_ALGO_NAMES = {0: "k_conv_features_pc + k_fc_head (direct implicit GEMM, f32 MFMA)",
+                       2: "k_conv_features_wstream (Winograd F(2x2,3x3), f32 MFMA; cross-check build)",
+                       3: "k_conv_features_wsplit (Winograd, bf16 MFMA with 3-way operand split; cross-check build)",
                        4: "k_conv_features_h2 + k_fc_head_h2 (f16 hi/lo operand pairs, f16 MFMA, f32 accumulation)"}
 
     def conv_kernel_info(self):
         """Which conv/fc kernels this process launches and the matrix instructions they issue per cell (sv_conv_kernel_info)."""
         v = [C.c_int() for _ in range(5)]
-        _native.check(_native.lib().sv_conv_kernel_info(self._h, *[C.byref(x) for x in v]), "sv_conv_kernel_info")
+        self._check(self._lib.sv_conv_kernel_info(self._h, *[C.byref(x) for x in v]), "sv_conv_kernel_info")
         a = v[0].value
         return {"algo": a, "name": self.CONV_ALGO_NAMES.get(a, str(a)), "mfma_conv2": v[1].value, "mfma_conv1": v[2].value,
                 "mfma_f16_conv": v[3].value, "mfma_f16_fc": v[4].value}
@@ -116,19 +136,19 @@ class Context:
         bgr, pitch, fstride = _frame_layout(bgr)
         n, H, W = bgr.shape[0], bgr.shape[1], bgr.shape[2]
         out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_gray_u8(self._h, _ptr(bgr), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_gray_u8")
+        self._check(self._lib.sv_gray_u8(self._h, _ptr(bgr), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_gray_u8")
         return out
 
     def blur(self, gray, ksize):
         n, H, W = gray.shape
         out = torch.empty_like(gray)
-        _native.check(_native.lib().sv_blur_u8(self._h, _ptr(gray), n, H, W, int(ksize), _ptr(out), _stream_ptr()), "sv_blur_u8")
+        self._check(self._lib.sv_blur_u8(self._h, _ptr(gray), n, H, W, int(ksize), _ptr(out), _stream_ptr()), "sv_blur_u8")
         return out
 
     def adaptive_threshold(self, gray, block_size, c, inv=True):
         n, H, W = gray.shape
         out = torch.empty_like(gray)
-        _native.check(_native.lib().sv_adaptive_threshold_u8(self._h, _ptr(gray), n, H, W, int(block_size), float(c), int(bool(inv)),
+        self._check(self._lib.sv_adaptive_threshold_u8(self._h, _ptr(gray), n, H, W, int(block_size), float(c), int(bool(inv)),
                                                              _ptr(out), _stream_ptr()), "sv_adaptive_threshold_u8")
         return out
 
@@ -139,9 +159,9 @@ class Context:
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
         if out is None:
             out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
-        elif out.shape != (n, H, W) or out.dtype != torch.uint8 or not out.is_contiguous():
-            raise TypeError("out must be a contiguous uint8 tensor of shape [n,H,W]")
-        _native.check(_native.lib().sv_preprocess_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
+        else:
+            self._out(out, (n, H, W), torch.uint8, "out")
+        self._check(self._lib.sv_preprocess_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_u8")
         return out
 
     def preprocess_and_warp_cells(self, frames, minv_dev, binary=None, cells=None):
@@ -149,20 +169,21 @@ class Context:
         that know the corners beforehand) -> (binary u8 [n,H,W], cells u8 [n,81,28,28])."""
         frames, pitch, fstride = _frame_layout(frames)
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
-        binary = torch.empty((n, H, W), dtype=torch.uint8, device=self.device) if binary is None else binary
-        cells = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device) if cells is None else cells
-        _native.check(_native.lib().sv_preprocess_warp_cells_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(binary), _ptr(minv_dev), _ptr(cells),
+        binary = torch.empty((n, H, W), dtype=torch.uint8, device=self.device) if binary is None else self._out(binary, (n, H, W), torch.uint8, "binary")
+        cells = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device) if cells is None else self._out(cells, (n, 81, 28, 28), torch.uint8, "cells")
+        self._check(self._lib.sv_preprocess_warp_cells_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(binary), _ptr(minv_dev), _ptr(cells),
                                                                 _stream_ptr()), "sv_preprocess_warp_cells_u8")
         return binary, cells
 
     def preprocess_mm(self, frames, want_mean=False):
         """preprocess() through the matrix-pipe formulation of K1 (sv_preprocess_mm_u8): the same binary, an independent implementation.
+        Only on a Context of the test-only library (Context(library=_native.lib_xcheck())).
         want_mean: also return the kernel's approximate local mean per pixel (f32 [n,H,W])."""
         frames, pitch, fstride = _frame_layout(frames)
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
         out = torch.empty((n, H, W), dtype=torch.uint8, device=self.device)
         mean = torch.zeros((n, H, W), dtype=torch.float32, device=self.device) if want_mean else None
-        _native.check(_native.lib().sv_preprocess_mm_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _ptr(mean) if want_mean else None,
+        self._check(self._lib.sv_preprocess_mm_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _ptr(mean) if want_mean else None,
                                                         _stream_ptr()), "sv_preprocess_mm_u8")
         return (out, mean) if want_mean else out
 
@@ -170,7 +191,7 @@ class Context:
         """(pixels decided by the exact evaluation in preprocess_mm launches since the last call, 0); the first call switches the counter on.
         Synchronises."""
         a, c = C.c_uint(), C.c_ulong()
-        _native.check(_native.lib().sv_preprocess_stats(self._h, C.byref(a), C.byref(c)), "sv_preprocess_stats")
+        self._check(self._lib.sv_preprocess_stats(self._h, C.byref(a), C.byref(c)), "sv_preprocess_stats")
         return a.value, c.value
 
     def preprocess_bits(self, frames, out=None):
@@ -180,14 +201,14 @@ class Context:
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
         if W % 32:
             raise ValueError("preprocess_bits needs W % 32 == 0")
-        out = torch.empty((n, H, W // 32), dtype=torch.int32, device=self.device) if out is None else out
-        _native.check(_native.lib().sv_preprocess_bits_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_bits_u8")
+        out = torch.empty((n, H, W // 32), dtype=torch.int32, device=self.device) if out is None else self._out(out, (n, H, W // 32), torch.int32, "out")
+        self._check(self._lib.sv_preprocess_bits_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(out), _stream_ptr()), "sv_preprocess_bits_u8")
         return out
 
     def despeckle_bits(self, bits):
         """despeckle on a bit image int32 [n,H,W//32], in place."""
         n, H, wpr = bits.shape
-        _native.check(_native.lib().sv_despeckle_bits(self._h, _ptr(bits), n, H, wpr * 32, _stream_ptr()), "sv_despeckle_bits")
+        self._check(self._lib.sv_despeckle_bits(self._h, _ptr(bits), n, H, wpr * 32, _stream_ptr()), "sv_despeckle_bits")
         return bits
 
     def despeckle(self, binary, out=None, packed=None):
@@ -196,7 +217,7 @@ class Context:
         tensor receiving the result as 1 bit per pixel (then `out` is scratch)."""
         n, H, W = binary.shape
         out = torch.empty_like(binary) if out is None else out
-        _native.check(_native.lib().sv_despeckle_u8(self._h, _ptr(binary), n, H, W, _ptr(out), _ptr(packed) if packed is not None else None,
+        self._check(self._lib.sv_despeckle_u8(self._h, _ptr(binary), n, H, W, _ptr(out), _ptr(packed) if packed is not None else None,
                                                     _stream_ptr()), "sv_despeckle_u8")
         return out if packed is None else packed
 
@@ -207,7 +228,7 @@ class Context:
         n, H, wpr = bits.shape
         if records.dtype != torch.uint8 or records.dim() != 2 or records.shape[0] < n or not records.is_contiguous() or not bits.is_contiguous():
             raise TypeError("records must be a contiguous uint8 [>=n, stride] device tensor")
-        _native.check(_native.lib().sv_pack_sparse_bits(self._h, _ptr(bits), n, H, wpr * 32, _ptr(records), records.shape[1], _stream_ptr()),
+        self._check(self._lib.sv_pack_sparse_bits(self._h, _ptr(bits), n, H, wpr * 32, _ptr(records), records.shape[1], _stream_ptr()),
                       "sv_pack_sparse_bits")
         return records[:n]
 
@@ -220,7 +241,7 @@ class Context:
         nbytes = src.numel() * src.element_size()
         if nbytes != dst.numel() * dst.element_size():
             raise ValueError("size mismatch")
-        _native.check(_native.lib().sv_copy_to_pinned_host(self._h, _ptr(src), _ptr(dst), nbytes, _stream_ptr()), "sv_copy_to_pinned_host")
+        self._check(self._lib.sv_copy_to_pinned_host(self._h, _ptr(src), _ptr(dst), nbytes, _stream_ptr()), "sv_copy_to_pinned_host")
         return dst
 
     # ---- K2 -----------------------------------------------------------------------------------
@@ -252,7 +273,7 @@ class Context:
         ch = 1 if img.dim() == 2 else img.shape[2]
         shape = (output_size, output_size) if img.dim() == 2 else (output_size, output_size, ch)
         out = torch.empty(shape, dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_warp_perspective_u8(self._h, _ptr(img), H, W, W * ch, ch, _ptr(minv_dev), int(output_size), _ptr(out),
+        self._check(self._lib.sv_warp_perspective_u8(self._h, _ptr(img), H, W, W * ch, ch, _ptr(minv_dev), int(output_size), _ptr(out),
                                                            _stream_ptr()), "sv_warp_perspective_u8")
         return out
 
@@ -260,7 +281,7 @@ class Context:
         h, w = grid.shape[0], grid.shape[1]
         ch = 1 if grid.dim() == 2 else grid.shape[2]
         out = torch.empty((81, cell_size, cell_size), dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_extract_cells_u8(self._h, _ptr(grid), h, w, w * ch, ch, int(cell_size), int(margin_h), int(margin_w),
+        self._check(self._lib.sv_extract_cells_u8(self._h, _ptr(grid), h, w, w * ch, ch, int(cell_size), int(margin_h), int(margin_w),
                                                         _ptr(out), _stream_ptr()), "sv_extract_cells_u8")
         return out
 
@@ -268,7 +289,7 @@ class Context:
         frames, pitch, fstride = _frame_layout(frames)
         n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
         out = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_warp_cells_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(minv_dev), _ptr(out), _stream_ptr()),
+        self._check(self._lib.sv_warp_cells_u8(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(minv_dev), _ptr(out), _stream_ptr()),
                       "sv_warp_cells_u8")
         return out
 
@@ -279,7 +300,7 @@ class Context:
         """cv2.resize(img, dsize=(w, h)) INTER_LINEAR on a gray u8 image."""
         dw, dh = dsize
         out = torch.empty((dh, dw), dtype=torch.uint8, device=self.device)
-        _native.check(_native.lib().sv_resize_linear_u8(self._h, _ptr(img), img.shape[0], img.shape[1], img.shape[1], _ptr(out), dh, dw, _stream_ptr()),
+        self._check(self._lib.sv_resize_linear_u8(self._h, _ptr(img), img.shape[0], img.shape[1], img.shape[1], _ptr(out), dh, dw, _stream_ptr()),
                       "sv_resize_linear_u8")
         return out
 
@@ -288,7 +309,7 @@ class Context:
         B = cells.shape[0]
         ratio = torch.empty((B,), dtype=torch.float32, device=self.device)
         otsu = torch.empty((B,), dtype=torch.int32, device=self.device)
-        _native.check(_native.lib().sv_cell_ink_ratio_u8(self._h, _ptr(cells), B, int(cells[0].numel()), _ptr(ratio), _ptr(otsu), _stream_ptr()),
+        self._check(self._lib.sv_cell_ink_ratio_u8(self._h, _ptr(cells), B, int(cells[0].numel()), _ptr(ratio), _ptr(otsu), _stream_ptr()),
                       "sv_cell_ink_ratio_u8")
         return ratio, otsu
 
@@ -341,7 +362,7 @@ class Context:
         else:
             args = (None, VP(*[pb + l[1] for l in lay]), VP(*[pb + l[2] for l in lay]), VP(*[pb + l[3] for l in lay]),
                     (C.c_long * n)(*[l[4] for l in lay]), used)
-        _native.check(_native.lib().sv_jpeg_entropy_decode_batch(bufs, sizes, n, *args, C.c_void_p(pb + qoff), int(threads), status),
+        self._check(self._lib.sv_jpeg_entropy_decode_batch(bufs, sizes, n, *args, C.c_void_p(pb + qoff), int(threads), status),
                       "sv_jpeg_entropy_decode_batch")
         same = all((i.out_height, i.out_width) == (infos[0].out_height, infos[0].out_width) for i in infos)
         if same:
@@ -350,7 +371,7 @@ class Context:
         else:
             outs = [torch.empty((i.out_height, i.out_width, 3), dtype=torch.uint8, device=self.device) for i in infos]
         dev[qoff:qoff + 384 * n].copy_(pin[qoff:qoff + 384 * n], non_blocking=True)
-        lib, stream = _native.lib(), _stream_ptr()
+        lib, stream = self._lib, _stream_ptr()
         for i, (info, l) in enumerate(zip(infos, lay)):
             end = l[3] + 2 * (int(info.coef_count) if dense else used[i])
             dev[l[0]:end].copy_(pin[l[0]:end], non_blocking=True)
@@ -360,7 +381,7 @@ class Context:
             else:
                 rc = lib.sv_jpeg_reconstruct_sparse_bgr_u8(self._h, C.byref(info), C.c_void_p(db + l[1]), C.c_void_p(db + l[2]), C.c_void_p(db + l[3]), q,
                                                            _ptr(outs[i]), outs[i].stride(0), stream)
-            _native.check(rc, "sv_jpeg_reconstruct")
+            self._check(rc, "sv_jpeg_reconstruct")
         ev.record(torch.cuda.current_stream(self.device))
         self._jpeg_last_bytes = sum((l[3] - l[0]) + 2 * (int(i.coef_count) if dense else used[k]) for k, (i, l) in enumerate(zip(infos, lay))) / max(n, 1)
         return out if same else outs
@@ -379,13 +400,13 @@ class Context:
         qoff = (voff + 2 * (ncoef if dense else cap) + 63) // 64 * 64
         pin, dev, ev = self._jpeg_staging(qoff + 384)
         pb, db = pin.data_ptr(), dev.data_ptr()
-        lib = _native.lib()
+        lib = self._lib
         if dense:
-            _native.check(lib.sv_jpeg_entropy_decode(data, len(data), C.c_void_p(pb), C.c_void_p(pb + qoff), int(threads)), "sv_jpeg_entropy_decode")
+            self._check(lib.sv_jpeg_entropy_decode(data, len(data), C.c_void_p(pb), C.c_void_p(pb + qoff), int(threads)), "sv_jpeg_entropy_decode")
             end = 2 * ncoef
         else:
             used = C.c_long()
-            _native.check(lib.sv_jpeg_entropy_decode_sparse(data, len(data), C.c_void_p(pb), C.c_void_p(pb + 8 * nb), C.c_void_p(pb + voff), cap, C.byref(used),
+            self._check(lib.sv_jpeg_entropy_decode_sparse(data, len(data), C.c_void_p(pb), C.c_void_p(pb + 8 * nb), C.c_void_p(pb + voff), cap, C.byref(used),
                                                             C.c_void_p(pb + qoff), int(threads)), "sv_jpeg_entropy_decode_sparse")
             end = voff + 2 * used.value
         dev[:end].copy_(pin[:end], non_blocking=True)
@@ -397,7 +418,7 @@ class Context:
         else:
             rc = lib.sv_jpeg_reconstruct_sparse_bgr_u8(self._h, C.byref(info), C.c_void_p(db), C.c_void_p(db + 8 * nb), C.c_void_p(db + voff), C.c_void_p(db + qoff),
                                                        _ptr(out), out.stride(0), _stream_ptr())
-        _native.check(rc, "sv_jpeg_reconstruct")
+        self._check(rc, "sv_jpeg_reconstruct")
         ev.record(torch.cuda.current_stream(self.device))
         return out
 
@@ -407,13 +428,13 @@ class Context:
         B = logits.shape[0]
         index = torch.empty((B, k), dtype=torch.uint8, device=self.device)
         prob = torch.empty((B, k), dtype=torch.float32, device=self.device)
-        _native.check(_native.lib().sv_softmax_topk_f32(self._h, _ptr(logits), B, int(k), _ptr(index), _ptr(prob), _stream_ptr()), "sv_softmax_topk_f32")
+        self._check(self._lib.sv_softmax_topk_f32(self._h, _ptr(logits), B, int(k), _ptr(index), _ptr(prob), _stream_ptr()), "sv_softmax_topk_f32")
         return index, prob
 
     def preprocess_cells(self, cells):
         """run.py's preprocess_cell on u8 cells [B,28,28] -> u8 {0,255} [B,28,28]."""
         out = torch.empty_like(cells)
-        _native.check(_native.lib().sv_preprocess_cells_u8(self._h, _ptr(cells), cells.shape[0], _ptr(out), _stream_ptr()), "sv_preprocess_cells_u8")
+        self._check(self._lib.sv_preprocess_cells_u8(self._h, _ptr(cells), cells.shape[0], _ptr(out), _stream_ptr()), "sv_preprocess_cells_u8")
         return out
 
     def cnn_forward(self, x, want_digits=False, glue=0):
@@ -425,10 +446,10 @@ class Context:
         conf = torch.empty((B,), dtype=torch.float32, device=self.device) if want_digits else None
         dg, cf = (_ptr(digits) if want_digits else None), (_ptr(conf) if want_digits else None)
         if x.dtype == torch.uint8:
-            rc = _native.lib().sv_cnn_forward_cells_u8(self._h, _ptr(x), B, int(glue), _ptr(logits), dg, cf, _stream_ptr())
+            rc = self._lib.sv_cnn_forward_cells_u8(self._h, _ptr(x), B, int(glue), _ptr(logits), dg, cf, _stream_ptr())
         else:
-            rc = _native.lib().sv_cnn_forward_f32(self._h, _ptr(x), B, _ptr(logits), dg, cf, _stream_ptr())
-        _native.check(rc, "sv_cnn_forward")
+            rc = self._lib.sv_cnn_forward_f32(self._h, _ptr(x), B, _ptr(logits), dg, cf, _stream_ptr())
+        self._check(rc, "sv_cnn_forward")
         return (logits, digits, conf) if want_digits else logits
 
     # ---- whole path ---------------------------------------------------------------------------
@@ -443,7 +464,7 @@ class Context:
             if keep_cells:
                 out["cells"] = torch.empty((n, 81, 28, 28), dtype=torch.uint8, device=self.device)
         cells = out.get("cells")
-        _native.check(_native.lib().sv_frames_to_digits(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(minv_dev), int(glue),
+        self._check(self._lib.sv_frames_to_digits(self._h, _ptr(frames), n, H, W, pitch, fstride, _ptr(minv_dev), int(glue),
                                                         _ptr(cells) if cells is not None else None, _ptr(out["logits"]), _ptr(out["digits"]),
                                                         _ptr(out["conf"]), _stream_ptr()), "sv_frames_to_digits")
         return out

@@ -29,7 +29,30 @@ def test_header_symbols_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(sva._native.SIGNATURES), "ctypes table and header disagree"
-    assert lib.sv_version() == 1
+    assert lib.sv_version() == sva._native.ABI_VERSION == 2
+
+
+def test_xcheck_library_is_a_superset_and_the_product_is_lean(lib):
+    """The test-only library exports everything the product does plus what include/sudoku_vision_xcheck.h declares; the product library
+    exports none of those extras (cross-check kernels are not shipped)."""
+    import sudoku_vision_amd as sva
+    x = sva._native.lib_xcheck()
+    hdr = open(os.path.join(ROOT, "include", "sudoku_vision_xcheck.h")).read()
+    extra = set(re.findall(r"\b(svx?_[a-z0-9_]+)\s*\(", hdr))
+    assert extra == set(sva._native.XCHECK_SIGNATURES)
+    for name in extra:
+        assert hasattr(x, name)
+        assert not hasattr(lib, name), f"{name} leaked into the product library"
+    for name in sva._native.SIGNATURES:
+        assert hasattr(x, name)
+
+
+def test_no_environment_switches_in_the_library():
+    """The C ABI's behaviour depends on its arguments and setters only."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "sudoku-vision_amd", "csrc", "*")):
+        if f.endswith((".hip", ".cpp", ".h")):
+            assert "getenv" not in open(f).read(), f
 
 
 def test_corners_to_minv_matches_oracle(lib):

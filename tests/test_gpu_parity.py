@@ -456,42 +456,97 @@ def test_bf16_configuration_digit_parity(golden_dir):
     c.close()
 
 
-def test_conv_algorithms_agree(golden_dir):
-    """Four independent conv2 (+ two fc1) implementations -- the default f16 hi/lo operand pairs on the f16 matrix pipe
-    (SV_CONV_ALGO=4, k3_cnn_h2.hip), Winograd stream on f32 MFMA (2), direct implicit GEMM on f32 MFMA (0) and the Winograd stream on
-    bf16 MFMA with three-way operand splitting (3) -- give the same logits to ~1e-5 and the same digits, and each is within 1e-4
-    of the PyTorch-CPU restatement (the default within 1e-5: its operand pairs carry 22 bits, its sums are f32); run in
-    subprocesses because the choice is read once per process."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import os, sys, numpy as np, torch\n"
-            f"sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'oracle'))\n"
-            "import sudoku_vision_amd as sva, cnn_oracle\n"
-            f"g = np.load(os.path.join({golden_dir!r}, 'cnn_coreml_fp16.npz'))\n"
-            "sd = {k: torch.from_numpy(g[k.replace('.', '_')].astype(np.float32)) for k in cnn_oracle.KEYS}\n"
-            "ctx = sva.default_context(); ctx.load_state_dict(sd)\n"
-            "x = torch.from_numpy(np.random.RandomState(1).randint(0, 256, (500, 28, 28)).astype(np.uint8)).cuda()\n"
-            "np.save(sys.argv[1], ctx.cnn_forward(x).cpu().numpy())\n")
+def _xctx():
+    """A context of the test-only superset library (cross-check kernels, include/sudoku_vision_xcheck.h)."""
+    import sudoku_vision_amd as sva
+    return sva.Context(library=sva._native.lib_xcheck())
+
+
+def test_conv_algorithms_agree(ctx, golden_dir):
+    """Four independent conv2 (+ three fc1) implementations -- the product's f16 hi/lo operand pairs on the f16 matrix pipe
+    (k3_cnn_h2.hip) and its f32-MFMA direct implicit GEMM (the kernels out-of-range inputs take), and the test-only library's Winograd
+    stream on f32 MFMA and on bf16 MFMA with three-way operand splitting -- give the same logits to ~1e-5 and the same digits, and each is
+    within 1e-4 of the PyTorch-CPU restatement (the default within 1e-5: its operand pairs carry 22 bits, its sums are f32).  The
+    selection is a context setter (sv_ctx_set_cnn_kernels); nothing is read from the environment."""
     g = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
     sd = {k: torch.from_numpy(g[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
-    cells = np.random.RandomState(1).randint(0, 256, (500, 28, 28)).astype(np.uint8)
+    cells = np.random.RandomState(1).randint(0, 256, (81 * 64 + 500, 28, 28)).astype(np.uint8)
     want = cnn_oracle.forward(sd, o.cells_to_input(cells)[:, None]).numpy()
+    x = torch.from_numpy(cells).cuda()
     outs = []
-    for algo in ("4", "2", "0", "3"):
-        path = f"/tmp/sv_conv_algo_{algo}.npy"
-        env = dict(os.environ, SV_CONV_ALGO=algo)
-        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(path))
-        assert np.abs(outs[-1] - want).max() <= (1e-5 if algo == "4" else LOGIT_TOL), algo
+    ctx.load_state_dict(sd)
+    for which, name in ((ctx.CNN_AUTO, "auto"), (ctx.CNN_F16PAIR, "f16 pairs"), (ctx.CNN_F32MFMA, "f32 mfma")):
+        ctx.set_cnn_kernels(which)
+        assert ctx.conv_kernel_info()["algo"] == (0 if which == ctx.CNN_F32MFMA else 4)
+        outs.append(ctx.cnn_forward(x).cpu().numpy())
+        assert np.abs(outs[-1] - want).max() <= (LOGIT_TOL if which == ctx.CNN_F32MFMA else 1e-5), name
+    ctx.set_cnn_kernels(ctx.CNN_AUTO)
+    assert np.array_equal(outs[0], outs[1])                          # trained weights are in range: auto = the f16-pair kernels
+    xc = _xctx()
+    xc.load_state_dict(sd)
+    for which, frame_fc in ((xc.CNN_X_WINOGRAD, 0), (xc.CNN_X_WSPLIT, 0), (xc.CNN_F32MFMA, 1), (xc.CNN_X_WINOGRAD, 1)):
+        xc.set_cnn_kernels(which)
+        xc._check(xc._lib.svx_ctx_set_fc_frame_kernel(xc._h, frame_fc), "svx_ctx_set_fc_frame_kernel")
+        outs.append(xc.cnn_forward(x).cpu().numpy())
+        assert np.abs(outs[-1] - want).max() <= LOGIT_TOL, (which, frame_fc)
+    xc.close()
     for other in outs[1:]:
         assert np.abs(outs[0] - other).max() <= 2e-5
         assert (outs[0].argmax(1) == other.argmax(1)).all()
 
 
+def test_cnn_has_the_reference_domain(ctx):
+    """ml/model.py:34-42 accepts any f32 tensor and any weights.  The f16-pair kernels carry inputs and activations as f16 pairs
+    (|v| < 65,504): with weights that push conv1's activations past that, and with f32 inputs far outside [-1, 1] or tiny, SV_CNN_AUTO
+    must still deliver the oracle's logits (relative 1e-4 of the logits' scale) -- by switching to the f32-MFMA kernels, at load time
+    for the weights and on the device per call for the inputs -- where the f16-pair kernels forced on the same data overflow."""
+    import sudoku_vision_amd as sva
+    rs = np.random.RandomState(5)
+    sd = {k: v.clone() for k, v in cnn_oracle.random_state_dict(77).items()}
+    c = sva.Context()
+
+    def rel_err(got, want):
+        return float(np.abs(got - want).max() / max(1.0, np.abs(want).max()))
+
+    cells = rs.randint(0, 256, (300, 28, 28)).astype(np.uint8)
+    x8 = o.cells_to_input(cells)[:, None]
+    # (1) weights: conv1 scaled so that its activations reach ~1e6
+    big = {k: v.clone() for k, v in sd.items()}
+    big["conv1.weight"] *= 3.0e6
+    c.load_state_dict(big)
+    assert c.conv_kernel_info()["algo"] == 0                         # decided when the weights were loaded
+    want = cnn_oracle.forward(big, x8).numpy()
+    assert np.isfinite(want).all() and np.abs(want).max() > 1e4
+    got = c.cnn_forward(torch.from_numpy(cells).cuda()).cpu().numpy()
+    assert np.isfinite(got).all() and rel_err(got, want) <= 1e-4
+    c.set_cnn_kernels(c.CNN_F16PAIR)                                 # the same through the f16-pair kernels: out of their range
+    bad = c.cnn_forward(torch.from_numpy(cells).cuda()).cpu().numpy()
+    assert not np.isfinite(bad).all() or rel_err(bad, want) > 1e-2
+    c.set_cnn_kernels(c.CNN_AUTO)
+    # (2) inputs: ordinary weights, f32 inputs of magnitude ~1e5, ~1e-6, with an Inf, and in range
+    c.load_state_dict(sd)
+    assert c.conv_kernel_info()["algo"] == 4
+    base = rs.uniform(-1, 1, (200, 1, 28, 28)).astype(np.float32)
+    for scale, tol in ((1.0e5, 1e-4), (1.0e-6, 1e-4), (1.0, 1e-5)):
+        x = torch.from_numpy(base * np.float32(scale))
+        want = cnn_oracle.forward(sd, x).numpy()
+        got = c.cnn_forward(x.cuda()).cpu().numpy()
+        assert np.isfinite(got).all() and rel_err(got, want) <= tol, scale
+    x = torch.from_numpy(base.copy())
+    x[3, 0, 5, 5] = float("inf")
+    want = cnn_oracle.forward(sd, x).numpy()
+    got = c.cnn_forward(x.cuda()).cpu().numpy()
+    ok = np.isfinite(want).all(1)
+    assert not ok[3] and ok.sum() == 199                             # the reference propagates the Inf into that cell's logits only
+    # (that cell's own logits are unspecified here: ReLU / max-pool are v_max, which drops a NaN where torch keeps it); every other cell
+    # of the batch is computed as if the Inf were not there
+    assert rel_err(got[ok], want[ok]) <= 1e-4
+    c.close()
+
+
 def test_cnn_large_batch_frame_kernel(ctx, golden_dir):
-    """B >= 5184 cells switches fc1 to the one-workgroup-per-frame kernel (LDS-staged weights); ragged tail included."""
+    """A batch of more than 64 frames' cells with a ragged tail (the round-1 frame-per-workgroup fc kernel switched in here; it now lives in
+    the test-only library, see test_conv_algorithms_agree)."""
     g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
     sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
     B = 81 * 64 + 37
@@ -648,9 +703,10 @@ def test_k1_matrix_pipe_form(ctx, H, W, kind):
     else:
         frames = torch.full((2, H, W, 3), 90, dtype=torch.uint8, device=ctx.device)
         frames[1, :, : W // 2] = 97
-    ctx.preprocess_stats()                                                        # switches the counter on / resets it
-    binary, mean = ctx.preprocess_mm(frames, want_mean=True)
-    redecided, _ = ctx.preprocess_stats()
+    xc = _xctx()                                                                  # the matrix-pipe K1 lives in the test-only library
+    xc.preprocess_stats()                                                         # switches the counter on / resets it
+    binary, mean = xc.preprocess_mm(frames, want_mean=True)
+    redecided, _ = xc.preprocess_stats()
     host = frames.cpu().numpy()
     taps = o.gaussian_kernel_f32(11).astype(np.float64)
     worst = 0.0

@@ -17,6 +17,7 @@ import sudoku_vision_amd as sva  # noqa: E402
 import sv_oracle as o  # noqa: E402
 
 ctx = sva.default_context()
+xctx = sva.Context(library=sva._native.lib_xcheck())                         # the test-only library: K1's matrix-pipe second implementation
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n1 = n2 = n3 = 0
 for it in range(60):                                                      # K1
@@ -48,7 +49,7 @@ for it in range(40):                                                      # K1's
     d = torch.from_numpy(np.clip(img, 0, 255).astype(np.uint8)).cuda()
     ref = ctx.preprocess(d)
     want = np.stack([o.preprocess_for_grid_detection(f) for f in d.cpu().numpy()])
-    if not (ref.cpu().numpy() == want).all() or not torch.equal(ctx.preprocess_mm(d), ref):
+    if not (ref.cpu().numpy() == want).all() or not torch.equal(xctx.preprocess_mm(d), ref):
         print("K1 matrix-pipe MISMATCH", n, H, W); sys.exit(1)
     if W % 32 == 0:
         bits = ctx.preprocess_bits(d)

@@ -182,6 +182,84 @@ def test_hipgraph_capture_replay_configs2(ctx, golden_dir):
     assert torch.cuda.mem_get_info()[0] == free0                           # replays allocate nothing (library scratch included)
 
 
+def _adversarial_binaries(H, W):
+    """{0,255} images built to break a component filter: a ring (area above the floor) with an island in its hole, a spiral inside one tile, a
+    spiral across many tiles, a large square touching the frame edges, a thin diagonal whose bounding box is above the area floor but whose
+    area is far below it, a quadrilateral just above the floor next to one just below it, everything buried in speck noise."""
+    rs = np.random.RandomState(H + W)
+    out = []
+    noise = (rs.uniform(size=(H, W)) < 0.004)
+    base = np.zeros((H, W), bool)
+    yy, xx = np.mgrid[:H, :W]
+    a = base.copy()                                                         # ring + island
+    a[H // 8:H - H // 8, W // 8:W - W // 8] = True
+    a[H // 8 + 6:H - H // 8 - 6, W // 8 + 6:W - W // 8 - 6] = False
+    a[H // 2 - 20:H // 2 + 20, W // 2 - 20:W // 2 + 20] = True
+    out.append(a | noise)
+    b = base.copy()                                                         # small spiral inside one 64x64 tile + a long spiral across tiles
+    for k in range(1, 14):
+        b[70 + 2 * k, 70 + 2 * k:130 - 2 * k] = True
+        b[70 + 2 * k:130 - 2 * k, 129 - 2 * k] = True
+    for k in range(0, min(H, W) // 2 - 40, 12):
+        b[20 + k, 150 + k:W - 20 - k] = True
+        b[20 + k:H - 20 - k, W - 21 - k] = True
+        b[H - 21 - k, 150 + k + 12:W - 20 - k] = True
+        b[20 + k + 12:H - 20 - k, 150 + k + 12] = True
+    out.append(b | noise)
+    c = base.copy()                                                         # a block touching the top and left frame edges, a second one the bottom right corner
+    c[0:H // 2, 0:W // 2] = True
+    c[H - H // 3:, W - W // 3:] = True
+    out.append(c | noise)
+    d = base.copy()                                                         # 3-px diagonal: bounding box ~ the whole frame, area tiny; plus a real quad
+    d[(abs(yy * W - xx * H) < 2 * max(H, W))] = True
+    d[H // 3:H // 3 + H // 3, W // 2 + 10:W // 2 + 10 + W // 3] = True
+    d[H // 3 + 4:H // 3 + H // 3 - 4, W // 2 + 14:W // 2 + 6 + W // 3] = False
+    out.append(d | noise)
+    e = base.copy()                                                         # two squares whose areas straddle 2 % of the frame
+    s_hi, s_lo = int(np.sqrt(0.02 * H * W)) + 3, int(np.sqrt(0.02 * H * W)) - 3
+    e[40:40 + s_hi, 40:40 + s_hi] = True
+    e[40 + 3:40 + s_hi - 3, 40 + 3:40 + s_hi - 3] = False
+    e[H - 40 - s_lo:H - 40, W - 40 - s_lo:W - 40] = True
+    out.append(e | noise)
+    out.append(noise | (rs.uniform(size=(H, W)) < 0.02))                    # no grid at all
+    return [(x * 255).astype(np.uint8) for x in out]
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (540, 960)])
+def test_filtered_search_equals_unfiltered(ctx, H, W):
+    """the corner search behind the GPU component filter (sv_despeckle_bits, in every hand-over form: byte image, bit image,
+    sparse records) returns exactly what the unfiltered search (cv/grid.py:37-71 on the raw binary) returns -- the same corners or None --
+    on adversarial images and on the synthetic golden frames, for min_area_ratio 0.1 (the reference's default) and 0.02.  The filter's
+    precondition (include/sudoku_vision_hip.h, sv_despeckle_u8): min_area_ratio * H * W > 61 * 61; both shapes and ratios satisfy it."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd.synth import synth_frames
+    imgs = _adversarial_binaries(H, W)
+    frames = synth_frames(3, H, W, seed=9, noise="int")[0].cuda()
+    imgs += list(ctx.preprocess(frames).cpu().numpy())
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    n = len(imgs)
+    filt = ctx.despeckle(d)
+    bits = torch.empty((n, H, W // 32), dtype=torch.int32, device="cuda")
+    ctx.despeckle(d, out=torch.empty_like(d), packed=bits)
+    cap = H * (W // 32) // 2
+    stride = sva.host.sparse_bits_record_bytes(H, W, cap)
+    recs = ctx.pack_sparse_bits(bits, torch.empty((n, stride), dtype=torch.uint8, device="cuda")).cpu().numpy()
+    fnp, bnp = filt.cpu().numpy(), bits.cpu().numpy()
+    some_found = 0
+    for ratio in (0.1, 0.02):
+        assert ratio * H * W > 61 * 61
+        cb, fb = sva.host.find_grid_corners_bits_batch(bnp, H, W, ratio, 0.02, 2)
+        cs, fs = sva.host.find_grid_corners_sparse_batch(recs, H, W, ratio, 0.02, 2)
+        for i in range(n):
+            want = sva.host.find_grid_corners(imgs[i], ratio)                # the unfiltered search on the raw binary
+            got_bytes = sva.host.find_grid_corners(fnp[i], ratio)
+            assert (want is None) == (got_bytes is None) and (want is None or (want == got_bytes).all()), (i, ratio)
+            assert bool(fb[i]) == (want is not None) and (want is None or (cb[i] == want).all()), (i, ratio)
+            assert fs[i] in (0, 1) and bool(fs[i]) == (want is not None) and (want is None or (cs[i] == want).all()), (i, ratio)
+            some_found += want is not None
+    assert some_found >= 8                                                   # the cases are not all trivially "None"
+
+
 def _bench(args, env=None, timeout=600):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=dict(os.environ, **(env or {})),
                        capture_output=True, text=True, timeout=timeout)

@@ -39,11 +39,11 @@ __device__ __forceinline__ u64 lane_shift_down(u64 v)   // lane i receives lane 
     const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x130, 0xf, 0xf, true);
     return ((u64)hi << 32) | lo;
 }
-// all bits of the runs of `f` that contain a bit of `g` (g subset of f)
-__device__ __forceinline__ u64 fill_runs(u64 f, u64 g)
+// all bits of the runs of `f` that contain a bit of `g` (g subset of f); fr = __brevll(f), hoisted by the caller
+__device__ __forceinline__ u64 fill_runs(u64 f, u64 fr, u64 g)
 {
     u64 up = ((f + g) ^ f) & f;                       // from each seed towards the MSB end of its run
-    const u64 fr = __brevll(f), gr = __brevll(g | up);
+    const u64 gr = __brevll(g | up);
     const u64 dn = ((fr + gr) ^ fr) & fr;             // and, bit-reversed, towards the LSB end
     return g | up | __brevll(dn);
 }
@@ -88,21 +88,23 @@ __device__ __forceinline__ u64 transpose64(u64 v, int lane)
 __device__ __forceinline__ u64 ring_connected(u64 f, int lane)
 {
     const u64 ring = (lane == 0 || lane == T - 1) ? ~0ull : 0x8000000000000001ull;      // the same mask in either orientation
-    u64 g = fill_runs(f, f & ring);
+    const u64 fr = __brevll(f);
+    u64 g = fill_runs(f, fr, f & ring);
     if (!__any(f != g)) return f;                                     // everything hangs on the ring already (or the tile is empty)
-    const u64 ft = transpose64(f, lane);
-    u64 cur = f;                                                      // the tile in the orientation g is in
-    bool transposed = false, converged = false;
+    if (!__any(g != 0)) return 0;                                     // nothing touches the ring: every component lies strictly inside
+    u64 ft = 0, ftr = 0;                                              // the transposed tile, made when the fill first has to turn
+    bool have_ft = false, transposed = false, converged = false;
     for (int it = 0; it < MAX_IT; it++) {
+        const u64 cur = transposed ? ft : f, curr = transposed ? ftr : fr;
         const u64 nb = g | lane_shift_up(g) | lane_shift_down(g);
         const u64 seeds = cur & (nb | (nb << 1) | (nb >> 1));          // 8-connectivity
-        const u64 g2 = fill_runs(cur, g | seeds);
+        const u64 g2 = fill_runs(cur, curr, g | seeds);
         const bool changed = g2 != g;
         g = g2;
         if (!__any(changed)) { converged = true; break; }
+        if (!have_ft) { ft = transpose64(f, lane); ftr = __brevll(ft); have_ft = true; }
         g = transpose64(g, lane);
         transposed = !transposed;
-        cur = transposed ? ft : f;
     }
     if (!converged) return f;
     return transposed ? transpose64(g, lane) : g;

@@ -148,7 +148,7 @@ def main():
                     help="f32 = BASELINE configs[1] (headline); bf16 = configs[4]: conv2/fc1 on bf16 MFMA, digit-index parity only")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end measurement: value = the device-only figure, value_kind says so")
     ap.add_argument("--e2e-passes", type=int, default=None, help="deprecated: 0 = --no-e2e")
-    ap.add_argument("--chunk", type=int, default=None, help="end-to-end pipeline: frames per chunk (default: largest of 128, 64, ... dividing --frames)")
+    ap.add_argument("--chunk", type=int, default=None, help="end-to-end pipeline: frames per chunk (default: largest of 256, 128, 64, ... dividing --frames)")
     ap.add_argument("--depth", type=int, default=None, help="end-to-end pipeline: chunks in flight")
     args = ap.parse_args()
     if args.steps is None:
@@ -253,7 +253,7 @@ def main():
         if budget > 16 * world:                      # no quota (or one far above the per-GPU share): split the host evenly over the ranks
             budget //= world
         host_threads = max(1, min(16, budget) - 2)
-        chunk = args.chunk or next(c for c in (128, 64, 32, 16, 8, 4, 2, 1) if n % c == 0)
+        chunk = args.chunk or next(c for c in (256, 128, 64, 32, 16, 8, 4, 2, 1) if n % c == 0)
         kw = {"depth": args.depth} if args.depth else {}
         pipe = FramePipeline(ctx, H, W, chunk=chunk, host_threads=host_threads, **kw)
         # warm-up: W steps, and at least 0.3 s of them (page-locks, worker threads and their scratch, host caches, GPU and CPU clocks after the

@@ -91,7 +91,9 @@ class FramePipeline:
         if self.packed:
             self.dev_bits = [torch.empty((chunk, H, W // 32), dtype=torch.int32, device=dev) for _ in range(depth)]
         if self.sparse:
-            cap = H * (W // 32) // 2 if sparse is True else int(sparse)          # an int: capacity in words (tests force the fallback with it)
+            # room for a third of the words (a synthetic 1080p frame keeps 13-15 k of its 64.8 k after the filter); an int: capacity in words
+            # (tests force the fallback with it).  Smaller records = fewer D2H bytes: 192 k frames/s against 187 k with room for half (tools/dev/e2e_knobs.py)
+            cap = H * (W // 32) // 3 if sparse is True else int(sparse)
             self.rec_bytes = host.sparse_bits_record_bytes(H, W, cap)
             self.pinned = [torch.empty((chunk, self.rec_bytes), dtype=torch.uint8).pin_memory() for _ in range(depth)]
             self.dev_rec = [torch.empty((chunk, self.rec_bytes), dtype=torch.uint8, device=dev) for _ in range(depth)]

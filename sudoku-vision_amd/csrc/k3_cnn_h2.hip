@@ -158,7 +158,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
         // window's 4 conv positions (weights shifted accordingly, zero where a tap falls outside the 3x3).  Two MFMAs per
         // (tile, position): [xh | xl] x [wh | wh]  and  [xh | xl] x [wl | 0].  The 4 positions are 4 accumulators of the same lane:
         // max, scale, bias, ReLU in the lane; the result is split into its f16 pair and stored channel-last for conv2.
-        const int chalf = (wave >> 1) & 1, ppar = wave & 1;                     // this wave: channels 16*chalf.., M tiles ppar, ppar+2, ...
+        // this wave: channels 16*chalf.., M tiles ppar, ppar+2, ...  The parity is the opposite of the consumer's on the same SIMD (waves w
+        // and w+4 share one): a cell has 13 M tiles, so one parity does 7 and the other 6, in conv1 and in conv2 alike, and a SIMD should not
+        // get the 7 of both (434 vs 372 MFMAs per cell before, 426 vs 380 now; the barrier waits for the slowest SIMD)
+        const int chalf = (wave >> 1) & 1, ppar = (wave & 1) ^ 1;
         uint4 b1reg[4][2];
 #pragma unroll
         for (int pos = 0; pos < 4; pos++)

@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256) void k_copy_to_host(const uint4 *__restrict__ 
 // one mask per row and group of 64 words (gpr = ceil(W/32/64) groups per row), bit k = word 64*group + k of the row is non-zero; the
 // non-zero words follow in raster order.  n_values > cap_values = the record overflowed (values truncated; the caller falls back to the
 // dense image).  One workgroup per frame: masks + counts, a scan of the counts in LDS, then the scatter.
+// KEEP: the frame's words stay in registers between the counting and the scatter phase (16 waves x TRIPS x 8 row groups >= G; a 1080p frame
+// is 1080 groups), so the image is read once; otherwise (taller frames) the scatter phase reads it again.
+template <bool KEEP>
 __global__ __launch_bounds__(1024) void k_pack_sparse(const u32 *__restrict__ bits, int H, int wpr, int gpr, u8 *__restrict__ records, long stride,
                                                       unsigned cap_values)
 {
@@ -209,18 +212,42 @@ __global__ __launch_bounds__(1024) void k_pack_sparse(const u32 *__restrict__ bi
     u64 *masks = (u64 *)(rec + 8);
     u32 *values = (u32 *)(rec + 8 + 8 * (size_t)G);
     // (U row groups per wave per trip, their loads issued together: one load per trip left the kernel waiting out a full memory latency 68 times)
-    constexpr int U = 8;
-    for (int g0 = wave * U; g0 < G; g0 += 16 * U) {
-        u32 w[U];
+    constexpr int U = 8, TRIPS = 9;
+    u32 kept[KEEP ? TRIPS : 1][U];
+    auto load_trip = [&](int g0, u32 (&w)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int g = g0 + u, y = g / gpr, k = (g - y * gpr) * 64 + lane;
             w[u] = (g < G && k < wpr) ? fb[(size_t)y * wpr + k] : 0u;
         }
+    };
+    auto count_trip = [&](int g0, const u32 (&w)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const u64 m = __ballot(w[u] != 0);
             if (lane == 0 && g0 + u < G) { masks[g0 + u] = m; cnt[g0 + u] = (u32)__popcll(m); }
+        }
+    };
+    auto scatter_trip = [&](int g0, const u32 (&w)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 m = __ballot(w[u] != 0);
+            if (w[u]) {                                          // (a non-zero word implies g0 + u < G)
+                const u32 pos = cnt[g0 + u] + (u32)__popcll(m & ((1ull << lane) - 1));
+                if (pos < cap_values) values[pos] = w[u];
+            }
+        }
+    };
+    if (KEEP) {
+#pragma unroll
+        for (int t = 0; t < TRIPS; t++) load_trip((t * 16 + wave) * U, kept[t]);
+#pragma unroll
+        for (int t = 0; t < TRIPS; t++) count_trip((t * 16 + wave) * U, kept[t]);
+    } else {
+        for (int g0 = wave * U; g0 < G; g0 += 16 * U) {
+            u32 w[U];
+            load_trip(g0, w);
+            count_trip(g0, w);
         }
     }
     __syncthreads();
@@ -240,20 +267,14 @@ __global__ __launch_bounds__(1024) void k_pack_sparse(const u32 *__restrict__ bi
     u32 run = base + incl - mine;
     for (int i = lo; i < hi; i++) { const u32 c = cnt[i]; cnt[i] = run; run += c; }
     __syncthreads();
-    for (int g0 = wave * U; g0 < G; g0 += 16 * U) {
-        u32 w[U];
+    if (KEEP) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int g = g0 + u, y = g / gpr, k = (g - y * gpr) * 64 + lane;
-            w[u] = (g < G && k < wpr) ? fb[(size_t)y * wpr + k] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const u64 m = __ballot(w[u] != 0);
-            if (w[u]) {                                          // (a non-zero word implies g0 + u < G)
-                const u32 pos = cnt[g0 + u] + (u32)__popcll(m & ((1ull << lane) - 1));
-                if (pos < cap_values) values[pos] = w[u];
-            }
+        for (int t = 0; t < TRIPS; t++) scatter_trip((t * 16 + wave) * U, kept[t]);
+    } else {
+        for (int g0 = wave * U; g0 < G; g0 += 16 * U) {
+            u32 w[U];
+            load_trip(g0, w);
+            scatter_trip(g0, w);
         }
     }
     if (tid == 0) { ((u32 *)rec)[0] = total; ((u32 *)rec)[1] = cap_values; }
@@ -277,8 +298,11 @@ int svk_pack_sparse_bits(const u32 *bits, int n, int H, int W, u8 *records, long
 {
     const int wpr = W >> 5, gpr = (wpr + 63) / 64, G = H * gpr;
     const long cap = (stride - 8 - 8L * G) / 4;
-    hipLaunchKernelGGL(k_pack_sparse, dim3((unsigned)n), dim3(1024), (size_t)(G + 16) * 4, s, bits, H, wpr, gpr, records, stride,
-                       (unsigned)(cap > 0xffffffffL ? 0xffffffffL : cap));
+    const unsigned capu = (unsigned)(cap > 0xffffffffL ? 0xffffffffL : cap);
+    if (G <= 16 * 9 * 8)
+        hipLaunchKernelGGL(k_pack_sparse<true>, dim3((unsigned)n), dim3(1024), (size_t)(G + 16) * 4, s, bits, H, wpr, gpr, records, stride, capu);
+    else
+        hipLaunchKernelGGL(k_pack_sparse<false>, dim3((unsigned)n), dim3(1024), (size_t)(G + 16) * 4, s, bits, H, wpr, gpr, records, stride, capu);
     SV_LAUNCH_CHECK("k_pack_sparse");
     return SV_OK;
 }

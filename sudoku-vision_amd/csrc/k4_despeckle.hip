@@ -165,22 +165,38 @@ __global__ __launch_bounds__(256) void k_despeckle(const u8 *__restrict__ src, u
 
 // The same filter on a bit image, in place (1 bit per pixel, LSB = leftmost, wpr = W/32 words per row): a tile row is two words.  Tiles of
 // one pass are disjoint, so reading and writing the same array is safe within a pass.
-__global__ __launch_bounds__(256) void k_despeckle_bits(u32 *__restrict__ bits, int H, int wpr, int ox, int oy, int tiles_x, int tiles_y, long ntiles)
+// TPW consecutive tiles of a tile row per wave, their words loaded up front: with one tile per wave the kernel was a chain of one memory
+// latency, one short computation and one store per wave, and 65,000 waves per pass of a 128-frame chunk.
+constexpr int TPW = 4;
+__global__ __launch_bounds__(256) void k_despeckle_bits(u32 *__restrict__ bits, int H, int wpr, int ox, int oy, int tiles_x, int tiles_y, long ngroups)
 {
     const int lane = threadIdx.x & 63;
-    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= ntiles) return;
-    const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
-    const long frame = tile / ((long)tiles_x * tiles_y);
-    const int k0 = (tx * T - ox) >> 5, y = ty * T - oy + lane;        // first word of the tile row (-1 for the first tile of the offset grid)
+    const long group = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (group >= ngroups) return;
+    const int gx = (tiles_x + TPW - 1) / TPW;                              // groups per tile row
+    const int tg = (int)(group % gx), ty = (int)((group / gx) % tiles_y);
+    const long frame = group / ((long)gx * tiles_y);
+    const int y = ty * T - oy + lane;
     const bool row_ok = y >= 0 && y < H;
     u32 *row = bits + (frame * H + (row_ok ? y : 0)) * (long)wpr;
-    const bool ok0 = row_ok && k0 >= 0 && k0 < wpr, ok1 = row_ok && k0 + 1 < wpr;
-    const u64 f = (ok0 ? (u64)row[k0] : 0ull) | (ok1 ? (u64)row[k0 + 1] << 32 : 0ull);
-    const u64 keep = ring_connected(f, lane);
-    if (keep == f) return;
-    if (ok0 && (u32)keep != (u32)f) row[k0] = (u32)keep;
-    if (ok1 && (u32)(keep >> 32) != (u32)(f >> 32)) row[k0 + 1] = (u32)(keep >> 32);
+    u64 f[TPW];
+    bool ok0[TPW], ok1[TPW];
+    int k0[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        const int tx = tg * TPW + t;
+        k0[t] = (tx * T - ox) >> 5;                                        // first word of the tile row (-1 for the first tile of the offset grid)
+        ok0[t] = row_ok && tx < tiles_x && k0[t] >= 0 && k0[t] < wpr;
+        ok1[t] = row_ok && tx < tiles_x && k0[t] + 1 < wpr;
+        f[t] = (ok0[t] ? (u64)row[k0[t]] : 0ull) | (ok1[t] ? (u64)row[k0[t] + 1] << 32 : 0ull);
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        const u64 keep = ring_connected(f[t], lane);
+        if (keep == f[t]) continue;
+        if (ok0[t] && (u32)keep != (u32)f[t]) row[k0[t]] = (u32)keep;
+        if (ok1[t] && (u32)(keep >> 32) != (u32)(f[t] >> 32)) row[k0[t] + 1] = (u32)(keep >> 32);
+    }
 }
 
 // Device -> mapped pinned host memory with plain 16-byte stores.  On this platform the shader's PCIe writes run at ~55 GB/s where
@@ -287,8 +303,8 @@ int svk_despeckle_bits(uint32_t *bits, int n, int H, int W, hipStream_t s)
     for (int pass = 0; pass < 2; pass++) {
         const int o = pass ? T / 2 : 0;
         const int tiles_x = (W + o + T - 1) / T, tiles_y = (H + o + T - 1) / T;
-        const long ntiles = (long)n * tiles_x * tiles_y;
-        hipLaunchKernelGGL(k_despeckle_bits, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, bits, H, W >> 5, o, o, tiles_x, tiles_y, ntiles);
+        const long ngroups = (long)n * ((tiles_x + TPW - 1) / TPW) * tiles_y;
+        hipLaunchKernelGGL(k_despeckle_bits, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, bits, H, W >> 5, o, o, tiles_x, tiles_y, ngroups);
         SV_LAUNCH_CHECK("k_despeckle_bits");
     }
     return SV_OK;

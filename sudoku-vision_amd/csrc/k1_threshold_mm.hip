@@ -5,7 +5,7 @@
 // kernel: 1.30 ms against 0.64 ms per 256 1080p frames.  Why it loses, measured (stage timestamps of one workgroup): a 64 x 128 tile needs
 // an 80 x 144 gray region (1.41x the pixels: 39 % of the kernel's VALU work is gray conversion, against 15 % in the marching kernel, whose
 // halo is 6 %), and five short passes separated by barriers with five or six MFMA jobs per wave each are latency, not throughput: 13 % S0,
-// 8 % S1, 10 % S2, 25 % S3, 26 % S4, 12 % exact re-decision, 6 % output.  Kept (entry sv_preprocess_mm_u8, SV_K1_ALGO=1) as an independent
+// 8 % S1, 10 % S2, 25 % S3, 26 % S4, 12 % exact re-decision, 6 % output.  Kept (entry sv_preprocess_mm_u8 of the test-only library libsudokuvision_xcheck.so) as an independent
 // second implementation of K1 for the tests, and as the record of the experiment.
 //
 // The idea: the marching kernel is VALU-issue bound (53.8 instructions per pixel, 0.64 ms per 256 1080p frames at 0.42 of the HBM roof),

@@ -475,6 +475,11 @@ __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__
 
 }  // namespace
 
+#ifdef SV_DEV
+// development builds (make FLAGS+=-DSV_DEV): the ablation / stamp bits of k_conv_features_h2, see svk_cnn_forward_h2
+extern "C" int sv_dev_set_h2_ablate(sv_ctx *ctx, int bits) { if (!ctx) return SV_ERR_BAD_ARG; ctx->dev_ablate = bits; return SV_OK; }
+#endif
+
 int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *logits, u8 *digits, float *conf, const int *run_if_clear, hipStream_t s)
 {
     const sv_weights &w = ctx->w;

@@ -34,8 +34,9 @@ def main():
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0)
     local = torch.stack(digs) if digs else torch.zeros((0, 81), dtype=torch.uint8)
     full = sharding.gather_digits(local, n_total, rank, world)
+    ranks = sharding.gather_objects({"rank": rank, "local_rank": local_rank, "pid": os.getpid()})    # what bench.py's `ranks` field is made of
     if rank == 0:
-        print(json.dumps({"n_gpus": world, "elapsed": elapsed, "digits": full.numpy().tolist()}), flush=True)
+        print(json.dumps({"n_gpus": world, "elapsed": elapsed, "digits": full.numpy().tolist(), "ranks": ranks}), flush=True)
     sharding.shutdown()
 
 

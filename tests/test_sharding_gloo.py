@@ -96,6 +96,8 @@ def test_launch_local_ranks_world2(tmp_path):
         assert sharding.launch_local_ranks(2, [worker, "5"], rank0_stdout=f) == 0
     res = json.loads(out.read_text().strip().splitlines()[-1])
     assert res["n_gpus"] == 2 and res["elapsed"] >= 0.1                  # the slower rank sleeps 0.1 s: MAX over ranks
+    assert [r["rank"] for r in res["ranks"]] == [0, 1] and [r["local_rank"] for r in res["ranks"]] == [0, 1]    # gather_objects: rank order
+    assert len({r["pid"] for r in res["ranks"]}) == 2
     frames, corners, _ = synth_frames(5, 135, 240, seed=5)
     sd = random_state_dict(3)
     for i in range(5):

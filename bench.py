@@ -256,11 +256,12 @@ def main():
         chunk = args.chunk or next(c for c in (256, 128, 64, 32, 16, 8, 4, 2, 1) if n % c == 0)
         kw = {"depth": args.depth} if args.depth else {}
         pipe = FramePipeline(ctx, H, W, chunk=chunk, host_threads=host_threads, **kw)
-        # warm-up: W steps, and at least 0.3 s of them (page-locks, worker threads and their scratch, host caches, GPU and CPU clocks after the
-        # idle stretch in which the pipeline's buffers were allocated: a first region started cold runs 40 % slower than the following ones)
+        # warm-up: W steps, and at least 1 s of them (page-locks, worker threads and their scratch, host caches, GPU and CPU clocks after the
+        # idle stretch in which the pipeline's buffers were allocated: regions started 0.3 s into the streaming still climbed, e.g. 144 k ->
+        # 168 k -> 193 k frames/s on one box; profiles/r03_e_bench.json)
         t_w = time.perf_counter()
         pipe.run(frames, out=out, total=max(n, min(mine, n) * args.warmup))
-        while time.perf_counter() - t_w < 0.3 and args.warmup > 0:
+        while time.perf_counter() - t_w < 1.0 and args.warmup > 0:
             pipe.run(frames, out=out, total=max(n, min(mine, 8 * n)))
         # three timed regions of exactly K steps; value = their median and all three are listed: on a shared host a region now and then
         # contains a 40-60 ms stall of one search call (tools/dev/search_outliers.py: with or without GPU work in flight), which says

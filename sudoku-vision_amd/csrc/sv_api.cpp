@@ -104,6 +104,8 @@ extern "C" int sv_ctx_set_precision(sv_ctx *ctx, int precision)
 extern "C" int sv_ctx_reserve(sv_ctx *ctx, long max_cells)
 {
     if (!ctx || max_cells <= 0) return sv_fail(SV_ERR_BAD_ARG, "sv_ctx_reserve: bad argument");
+    SV_HIP(hipSetDevice(ctx->device));
+    if (!ctx->range_flag) SV_HIP(hipMalloc((void **)&ctx->range_flag, 2 * sizeof(int)));     // sv_cnn_forward_f32's per-call range flag: no hipMalloc after reserve
     return sv_ensure_scratch(ctx, max_cells);
 }
 

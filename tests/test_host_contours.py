@@ -310,3 +310,46 @@ def test_sparse_record_validation(host):
     out = np.zeros(8, np.int32); fo = np.zeros(1, np.uint8)
     assert lib.sv_find_grid_corners_sparse_batch(good.ctypes.data_as(C.c_void_p), C.c_long(64), 1, H, W, C.c_double(0.01), C.c_double(0.02),
                                                  out.ctypes.data_as(C.c_void_p), fo.ctypes.data_as(C.c_void_p), 1) == -1
+
+
+@pytest.mark.parametrize("H,W", [(96, 128), (70, 2080), (130, 4128)])
+def test_sparse_search_sequences_on_one_thread(host, H, W):
+    """The per-thread scratch of the bit scanner survives from frame to frame (the image is rewritten chunk by chunk where the old or the new
+    frame has words, labels are cleared through a touched list): sequences of very different frames on ONE thread -- dense, empty, shifted,
+    sparse, the same again -- through the sparse entry and the dense entry in turn, every answer against the byte scanner; and the
+    contour lists of the bit and byte scanners on random images of many densities."""
+    rng = np.random.RandomState(H * W)
+
+    def frame(kind, seed):
+        rs = np.random.RandomState(seed)
+        if kind == "empty":
+            return np.zeros((H, W), bool)
+        if kind == "full":
+            return np.ones((H, W), bool)
+        b = rs.rand(H, W) < {"sparse": 0.002, "mid": 0.08, "dense": 0.45}[kind]
+        if seed % 2:
+            y0, x0 = rs.randint(2, H // 3), rs.randint(2, W // 3)
+            b[y0:H - 3, x0:x0 + 3] = True
+            b[y0:H - 3, W - 8:W - 5] = True
+            b[y0:y0 + 3, x0:W - 5] = True
+            b[H - 6:H - 3, x0:W - 5] = True
+        return b
+    kinds = ["dense", "empty", "sparse", "mid", "full", "sparse", "empty", "mid", "dense", "mid"]
+    words = H * (W // 32)
+    for i, kind in enumerate(kinds * 2):
+        b = frame(kind, i)
+        img = (b * 255).astype(np.uint8)
+        bits = np.ascontiguousarray(np.packbits(b, axis=1, bitorder="little").view(np.uint32))
+        want = host.find_grid_corners(img, 0.05)
+        if i % 3 == 2:                                            # the dense entry in between: it shares the scratch with the sparse one
+            c, f = host.find_grid_corners_bits_batch(bits[None], H, W, 0.05, 0.02, 1)
+        else:
+            rec = _pack_sparse_np(host, bits, words)
+            c, f = host.find_grid_corners_sparse_batch(rec[None], H, W, 0.05, 0.02, 1)
+            assert f[0] in (0, 1)
+        assert bool(f[0]) == (want is not None) and (want is None or (c[0] == want).all()), (i, kind)
+    for density in (0.001, 0.01, 0.1, 0.3, 0.5, 0.7, 0.97):
+        b = rng.rand(H, W) < density
+        a = host.find_contours((b * 255).astype(np.uint8))
+        g = host.find_contours_bits(np.ascontiguousarray(np.packbits(b, axis=1, bitorder="little").view(np.uint32)), H, W)
+        assert len(a) == len(g) and all(np.array_equal(x, y) for x, y in zip(a, g)), density

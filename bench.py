@@ -47,9 +47,9 @@ F16_MFMA_PEAK = 2.5e15               # FLOP/s dense, v_mfma_f32_*_f16 (same rate
 def issued_flop_per_cell(info):
     """FLOPs the CNN kernels ISSUE per cell (what their roofline fractions are priced on) -> (conv, fc, peak FLOP/s of the pipe).
     Default pair (algo 4): v_mfma_f32_16x16x32_f16 instructions (16384 FLOP each; three partial products per f32-grade product,
-    conv1's K padded 16 -> 32) against the dense f16 MFMA peak.  f32-MFMA kernels: conv2 by Winograd F(2x2,3x3) (1568
-    v_mfma_f32_16x16x4_f32 of 2048 FLOP, where the direct convolution needs 3600) or direct, conv1 and the Winograd transforms' adds on
-    the VALU, fc1 as 802,816 FLOP padded 81 -> 96 rows, against the f32 MFMA peak."""
+    conv1's K padded 16 -> 32) against the dense f16 MFMA peak.  f32-MFMA kernels (what out-of-range weights run on; the test-only library's
+    Winograd forms too): conv2 direct (3600 v_mfma_f32_16x16x4_f32 of 2048 FLOP per cell) or by Winograd F(2x2,3x3) (1568), conv1 and the
+    Winograd transforms' adds on the VALU, fc1's 802,816 FLOP per cell, against the f32 MFMA peak."""
     if info["mfma_f16_conv"]:
         return info["mfma_f16_conv"] * 16384, info["mfma_f16_fc"] * 16384, F16_MFMA_PEAK
     conv = (info["mfma_conv2"] + info["mfma_conv1"]) * 2048
@@ -57,7 +57,7 @@ def issued_flop_per_cell(info):
         conv += 451_584
     if info["algo"] == 2:
         conv += 49 * 32 * 32 + 49 * 64 * 24
-    return conv, FC_FLOP_PER_CELL * 96 // 81, FP32_MFMA_PEAK
+    return conv, FC_FLOP_PER_CELL, FP32_MFMA_PEAK
 
 
 def cpu_baseline_test_image(sd, seconds=4.0):

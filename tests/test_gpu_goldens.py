@@ -392,10 +392,11 @@ def test_copy_to_pinned_host(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,W", [(1080, 1920), (270, 480), (96, 3648), (50, 4128)])
+@pytest.mark.parametrize("H,W", [(1080, 1920), (270, 480), (96, 3648), (50, 4128), (1300, 64), (700, 2112)])
 def test_sparse_bit_records_kernel(ctx, H, W):
     """sv_pack_sparse_bits against the numpy statement of the record format (tests/test_host_contours.py), empty to dense frames, with and
-    without overflow, one and two mask groups per row; and the records expand back to the dense image on the host."""
+    without overflow, one and two mask groups per row, frames whose row groups fit the kernel's register-resident form (<= 1152) and
+    frames that do not (1300 x 64, 700 x 2112); and the records expand back to the dense image on the host."""
     import sudoku_vision_amd as sva
     from test_host_contours import _pack_sparse_np
     rng = np.random.RandomState(H)

@@ -718,3 +718,24 @@ def test_k1_matrix_pipe_form(ctx, H, W, kind):
     assert worst < 4e-4, worst                   # the float64 sum is itself within 1.5e-4 of cv2's float chain; EPS is 1.95e-3
     assert torch.equal(binary, ctx.preprocess(frames))
     assert redecided < 0.02 * 2 * H * W + 64, redecided
+
+
+@pytest.mark.parametrize("H,W", [(2160, 3840), (720, 1280)])
+def test_pipeline_other_resolutions(ctx, H, W):
+    """FramePipeline end to end on 4K (two mask groups per row in the sparse records, 4320 row groups: the pack kernel's streaming form) and
+    720p frames: every grid found, corners equal to the plain search on K1's binary, digits equal to the device-only path."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd import synth
+    from sudoku_vision_amd.pipeline import FramePipeline
+    ctx.load_state_dict(synth.random_state_dict(1234))
+    frames, corners, _ = synth.synth_frames(5, H, W, seed=H, device=ctx.device)
+    pipe = FramePipeline(ctx, H, W, chunk=2, host_threads=3)
+    assert pipe.packed
+    out = pipe.run(frames)
+    torch.cuda.synchronize()
+    binary = ctx.preprocess(frames).cpu().numpy()
+    for i in range(5):
+        want = sva.host.find_grid_corners(binary[i])
+        assert want is not None and out["found"][i] and (out["corners"][i] == want).all()
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(out["corners"].astype(np.float32)))
+    assert torch.equal(out["digits"], ctx.frames_to_digits(frames, minv)["digits"])

@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -26,6 +27,7 @@
 namespace {
 
 struct Pt { int x, y; };
+typedef uint64_t __attribute__((may_alias)) u64a;   // 64-bit view of words stored as uint32_t
 
 const int kDx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
 const int kDy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
@@ -241,15 +243,50 @@ class BorderScanner {
 // BorderScanner::follow runs.  Per row, 64-bit masks say which words hold set pixels (from the sparse record, or built while the
 // dense image is copied in) and which hold right-exit labels, so both the run-start search and the jump across a followed interior
 // step from one interesting word to the next.
+// Growable array without value-initialisation: the border follower appends with "store, then advance the count by 0 or 1", which needs
+// room behind the count that costs nothing to provide.
+template <class T>
+struct RawBuf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    size_t size() const { return n; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    const T *begin() const { return p; }
+    const T *end() const { return p + n; }
+    void clear() { n = 0; }
+    void room(size_t extra)                     // p[n .. n + extra) may be written afterwards
+    {
+        if (n + extra <= cap) return;
+        size_t c = cap ? cap : 1024;
+        while (c < n + extra) c *= 2;
+        T *q = static_cast<T *>(realloc(p, c * sizeof(T)));
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = c;
+    }
+    void push_back(const T &v) { room(1); p[n++] = v; }
+};
+
 struct BitScratch {
-    std::vector<uint32_t> img;                  // [(H + 2) * (wpr + 2)] (+ slack for the vector expansion's full-group stores)
-    std::vector<uint32_t> lab;                  // label planes, interleaved: lab[2i] = T word i, lab[2i + 1] = R word i (one cache line per mark)
-    std::vector<uint64_t> bmask, rmask;         // [H * gpr]: words of the row with set pixels / with right-exit labels
-    struct Touched { uint32_t word, group; };   // label words (and their rmask group) written by the current frame's borders
-    std::vector<Touched> touched;
-    std::vector<Pt> points;
+    static constexpr int PADY = 2;              // zero rows above and below the image (the follower keeps rows y-2 .. y+2 in registers)
+    std::vector<uint32_t> img;                  // [(H + 2 PADY) * (wpr + 2)] (+ slack for the vector expansion's full-group stores)
+    // Labels, one block of lab_row words per padded row (H + 2 rows): first the row's right-exit masks (gpr 64-bit words: which label
+    // words of the row hold right-exit labels), then the two label planes interleaved (pair k: T word, R word of padded word k), so that
+    // the follower addresses everything it writes for a pixel from one row pointer and a mark touches one cache line (two at most).
+    std::vector<uint32_t> lab;
+    std::vector<uint64_t> bmask;                // [H * gpr]: words of the row with set pixels
+    struct Touched { uint32_t pair, rmask; };   // offsets into lab of a label pair / a right-exit mask written by the current frame's borders
+    RawBuf<Touched> touched;
+    RawBuf<Pt> points;
     std::vector<Contour> contours;
-    int h = 0, wpr = 0, gpr = 0, stride = 0;
+    int h = 0, wpr = 0, gpr = 0, stride = 0, lab_row = 0;
     bool dirty_img = false;
 
     static BitScratch &get() { static thread_local BitScratch s; return s; }
@@ -262,21 +299,22 @@ struct BitScratch {
         const int w = W >> 5;
         if (h != H || wpr != w) {               // (H, words per row) -- not their product: 480x640 and 640x480 share a word count
             h = H; wpr = w; gpr = (w + 63) / 64; stride = w + 2;
-            img.assign((size_t)(H + 2) * stride + 64, 0u);
-            lab.assign((size_t)(H + 2) * stride * 2, 0u);
+            img.assign((size_t)(H + 2 * PADY) * stride + 64, 0u);
+            lab_row = 2 * gpr + 2 * stride;
+            lab.assign((size_t)(H + 2) * lab_row, 0u);
             bmask.assign((size_t)H * gpr, 0ull);
-            rmask.assign((size_t)H * gpr, 0ull);
             touched.clear();
             dirty_img = false;
         }
         if (dirty_img && !keep_img) memset(img.data(), 0, img.size() * 4);
-        for (const Touched &x : touched) { lab[2 * (size_t)x.word] = 0; lab[2 * (size_t)x.word + 1] = 0; rmask[x.group] = 0; }
+        for (const Touched &x : touched) { lab[x.pair] = 0; lab[x.pair + 1] = 0; lab[x.rmask] = 0; lab[x.rmask + 1] = 0; }
         touched.clear();
         points.clear();
         contours.clear();
         dirty_img = true;
     }
-    uint32_t *row(int y) { return img.data() + (size_t)(y + 1) * stride + 1; }   // word 0 of image row y
+    uint32_t *row(int y) { return img.data() + (size_t)(y + PADY) * stride + 1; }   // word 0 of image row y
+    uint32_t *label_pairs(int y) { return lab.data() + (size_t)(y + 1) * lab_row + 2 * gpr; }   // pair of padded word 0 of row y (image word k = pair k + 1)
 
     // dense bit image (H rows of wpr words) -> padded image + row masks
     void load_dense(const uint32_t *bits)
@@ -295,10 +333,12 @@ struct BitScratch {
     }
 };
 
-// (3x3 neighbourhood, direction of the previous border pixel) -> next direction | right-neighbour-examined << 3; and the neighbourhood
-// as an 8-bit mask over the directions of kDx/kDy.  code9 = row above | row << 3 | row below << 6, each 3 bits (x-1, x, x+1).
+// (3x3 neighbourhood, direction of the previous border pixel) -> the step to the next border pixel, packed so that nothing on the
+// follower's latency chain has to be derived from the direction: bits 0-2 the direction back from the next pixel (the index of its own
+// look-up), bit 3 "the right neighbour was examined and is clear", bit 4 "the border turns here" (the pixel is a vertex of the compressed
+// chain), bits 8-9 dx + 1, bits 10-11 dy + 1; and the neighbourhood as an 8-bit mask over the directions of kDx/kDy.  code9 = row above | row << 3 | row below << 6, each 3 bits (x-1, x, x+1).
 struct FollowTable {
-    uint8_t next[512][8];
+    uint16_t next[512][8];
     uint8_t nb8[512];
     FollowTable()
     {
@@ -315,7 +355,7 @@ struct FollowTable {
                 }
                 s &= 7;
                 const bool right = (unsigned)(s - 1) < (unsigned)s_from;
-                next[c][s_from] = (uint8_t)(s | (right ? 8 : 0));
+                next[c][s_from] = (uint16_t)((s ^ 4) | (right ? 8 : 0) | (s != (s_from ^ 4) ? 16 : 0) | (kDx[s] + 1) << 8 | (kDy[s] + 1) << 10);
             }
         }
     }
@@ -343,8 +383,8 @@ class BitScanner {
             };
             int k = next_word(0);
             if (k >= wpr_) continue;                               // empty row
-            const size_t base = (size_t)(y + 1) * stride_ + 1;
-            const uint32_t *brow = img_ + base, *lrow = lab_ + 2 * base;      // lrow[2k] = T word k, lrow[2k + 1] = R word k
+            const uint32_t *brow = img_ + (size_t)(y + BitScratch::PADY) * stride_ + 1;
+            const uint32_t *lrow = sc_.label_pairs(y) + 2;                       // lrow[2k] = T word k, lrow[2k + 1] = R word k
             int x = 32 * k;
             for (;;) {
                 // next pixel >= x that is labelled or starts a run (brow[-1] is the zero pad word)
@@ -366,7 +406,7 @@ class BitScanner {
                 if (!(lrow[2 * (pos >> 5)] & m)) follow(pos, y);         // an unlabelled run start with no positive label pending: a new outer border
                 x = pos + 1;
                 if (!(lrow[2 * (pos >> 5) + 1] & m)) {               // positive label: nothing can start before the next right-exit label of the row
-                    const uint64_t *rm = sc_.rmask.data() + (size_t)y * gpr_;
+                    const u64a *rm = reinterpret_cast<const u64a *>(sc_.label_pairs(y)) - gpr_;
                     int nx = -1;
                     for (int kk = x >> 5; kk < wpr_;) {
                         uint64_t mm = rm[kk >> 6] >> (kk & 63);
@@ -385,68 +425,99 @@ class BitScanner {
     }
 
   private:
-    // 3x3 neighbourhood of pixel x in the padded row whose bytes start at rp (rows above / below are rb bytes away)
-    static inline unsigned code9(const uint8_t *rp, ptrdiff_t rb, int x)
-    {
-        const unsigned bit = (unsigned)x + 31u;                    // bit index of pixel x-1 in the padded row
-        const uint8_t *p = rp + (bit >> 3);
-        const unsigned sh = bit & 7;
-        uint32_t u, m, d;
-        memcpy(&u, p - rb, 4);
-        memcpy(&m, p, 4);
-        memcpy(&d, p + rb, 4);
-        return ((u >> sh) & 7) | (((m >> sh) & 7) << 3) | (((d >> sh) & 7) << 6);
-    }
-    // labels pixel x of the row whose label words start at lr (padded word 0) and whose rmask groups start at rmg
-    inline void mark(uint32_t *lr, uint64_t *rmg, int x, bool right)
-    {
-        const int k = (x >> 5) + 1;
-        const uint32_t m = 1u << (x & 31);
-        uint32_t *w = lr + 2 * k;
-        if (!w[0]) sc_.touched.push_back({(uint32_t)((w - lab_) >> 1), (uint32_t)(rmg - sc_.rmask.data() + (x >> 11))});
-        w[0] |= m;
-        if (right) { w[1] |= m; rmg[x >> 11] |= 1ull << ((x >> 5) & 63); }
-    }
-
-    // BorderScanner::follow on the bit planes (x, y are image coordinates; the byte scanner's are the same minus its padding)
+    // BorderScanner::follow on the bit planes (x, y are image coordinates; the byte scanner's are the same minus its padding).
+    // The loop's latency chain is neighbourhood -> table -> direction -> position -> neighbourhood, so the neighbourhood comes out of
+    // registers: five 64-bit windows hold bits [8 byte0, 8 byte0 + 64) of padded rows y-2 .. y+2.  A vertical step shifts the windows by
+    // one row and loads the new outer one (needed two steps later at the earliest); a horizontal step moves the bit position, and only
+    // when it leaves [1, 62] are the windows reloaded around it.  Everything else in the step is branch-free: the label planes, the
+    // touched list and the vertex list are written every time and change / advance only when they should.
     void follow(int sx, int sy)
     {
+        static_assert(sizeof(Pt) == 8, "a point is stored as one 64-bit word: x low, y high");
         Contour c{points.size(), 0, sx, sy, sx, sy};
-        const ptrdiff_t rb = (ptrdiff_t)stride_ * 4;
-        const uint8_t *rp = reinterpret_cast<const uint8_t *>(img_ + (size_t)(sy + 1) * stride_);
-        uint32_t *lr = lab_ + 2 * (size_t)(sy + 1) * stride_;
-        uint64_t *rmg = sc_.rmask.data() + (size_t)sy * gpr_;
-        const unsigned nb0 = kFollow.nb8[code9(rp, rb, sx)];
+        const ptrdiff_t rb = (ptrdiff_t)stride_ * 4, lrw = sc_.lab_row;
+        const uint8_t *img8 = reinterpret_cast<const uint8_t *>(img_);
+        uint32_t *lr = sc_.label_pairs(sy);
+        const uint8_t *wp;
+        uint64_t w0, w1, w2, w3, w4;
+        int pb;
+        auto load_windows = [&](uint32_t x, uint32_t y) {
+            const unsigned bit = x + 32u;                              // bit index of pixel x in the padded row (>= 32)
+            const unsigned byte0 = (bit >> 3) - 4u;                    // window = bytes [byte0, byte0 + 8): inside the row for every x in [0, W)
+            pb = (int)(bit - 8u * byte0);                              // 32 .. 39
+            wp = img8 + (ptrdiff_t)(y + BitScratch::PADY) * rb + byte0;
+            memcpy(&w0, wp - 2 * rb, 8);
+            memcpy(&w1, wp - rb, 8);
+            memcpy(&w2, wp, 8);
+            memcpy(&w3, wp + rb, 8);
+            memcpy(&w4, wp + 2 * rb, 8);
+        };
+        auto code9 = [&]() -> unsigned {
+            const unsigned sh = (unsigned)pb - 1u;
+            return (unsigned)((w1 >> sh) & 7) | (unsigned)(((w2 >> sh) & 7) << 3) | (unsigned)(((w3 >> sh) & 7) << 6);
+        };
+        // labels pixel x of the row whose label pairs start at lr: T always, R and the row's right-exit mask if `right`
+        auto &touched = sc_.touched;
+        BitScratch::Touched *tp = touched.p;
+        size_t tn = touched.n;
+        auto mark = [&](uint32_t x, uint32_t right) {
+            if (tn == touched.cap) { touched.n = tn; touched.room(1); tp = touched.p; }
+            uint32_t *w = lr + 2 * ((x >> 5) + 1);
+            u64a *g = reinterpret_cast<u64a *>(lr) - gpr_ + (x >> 11);
+            const uint32_t m = 1u << (x & 31);
+            tp[tn] = {(uint32_t)(w - lab_), (uint32_t)(reinterpret_cast<uint32_t *>(g) - lab_)};
+            tn += w[0] == 0;
+            w[0] |= m;
+            w[1] |= (0u - right) & m;
+            *g |= (uint64_t)right << ((x >> 5) & 63);
+        };
+        load_windows((uint32_t)sx, (uint32_t)sy);
+        const unsigned nb0 = kFollow.nb8[code9()];
         int s = 4;
         do {
             s = (s - 1) & 7;
         } while (!((nb0 >> s) & 1) && s != 4);
         if (s == 4) {  // isolated pixel (the start pixel's left neighbour is clear: it starts a run)
-            mark(lr, rmg, sx, true);
+            mark((uint32_t)sx, 1u);
             points.push_back({sx, sy});
         } else {
-            const int x2 = sx + kDx[s], y2 = sy + kDy[s];
-            int cx = sx, cy = sy;
-            int prev_dir = s ^ 4;
+            auto pack = [](int x, int y) { return (uint64_t)(uint32_t)y << 32 | (uint32_t)x; };
+            const uint64_t start = pack(sx, sy), second = pack(sx + kDx[s], sy + kDy[s]);
+            uint64_t pos = start;                                      // y << 32 | x: one add per step, one store per vertex
+            unsigned from = (unsigned)s;                               // direction (from the current pixel) of the pixel we came from
+            Pt *pp = points.p;
+            size_t np = points.n;
             for (;;) {
-                const unsigned e = kFollow.next[code9(rp, rb, cx)][s];
-                s = e & 7;
-                mark(lr, rmg, cx, (e & 8) != 0);
-                if (s != prev_dir) {
-                    points.push_back({cx, cy});
-                    c.x0 = std::min(c.x0, cx); c.x1 = std::max(c.x1, cx);
-                    c.y0 = std::min(c.y0, cy); c.y1 = std::max(c.y1, cy);
-                    prev_dir = s;
+                if (np == points.cap) { points.n = np; points.room(1); pp = points.p; }
+                const unsigned e = kFollow.next[code9()][from];
+                from = e & 7;
+                mark((uint32_t)pos, (e >> 3) & 1u);
+                memcpy(pp + np, &pos, 8);                              // kept iff the border turns here
+                np += (e >> 4) & 1u;
+                const int dx = (int)((e >> 8) & 3u) - 1, dy = (int)(e >> 10) - 1;
+                const uint64_t npos = pos + (uint64_t)(int64_t)dx + ((uint64_t)(int64_t)dy << 32);
+                if (npos == start && pos == second) break;
+                pos = npos;
+                pb += dx;
+                if (dy > 0) {
+                    w0 = w1; w1 = w2; w2 = w3; w3 = w4;
+                    wp += rb; lr += lrw;
+                    memcpy(&w4, wp + 2 * rb, 8);
+                } else if (dy < 0) {
+                    w4 = w3; w3 = w2; w2 = w1; w1 = w0;
+                    wp -= rb; lr -= lrw;
+                    memcpy(&w0, wp - 2 * rb, 8);
                 }
-                // kDx[s], kDy[s] out of two packed constants (2 bits per direction, value + 1): the step is on the loop's latency chain
-                const int dy = (int)((0xA901u >> (2 * s)) & 3u) - 1;
-                const int nx = cx + (int)((0x901Au >> (2 * s)) & 3u) - 1, ny = cy + dy;
-                if (nx == sx && ny == sy && cx == x2 && cy == y2) break;
-                cx = nx; cy = ny;
-                rp += dy * rb; lr += dy * 2 * (ptrdiff_t)stride_; rmg += dy * (ptrdiff_t)gpr_;
-                s = (s + 4) & 7;
+                if ((unsigned)(pb - 1) > 61u) load_windows((uint32_t)pos, (uint32_t)(pos >> 32));
+            }
+            points.n = np;
+            for (size_t i = c.first; i < np; i++) {
+                const Pt q = pp[i];
+                c.x0 = std::min(c.x0, q.x); c.x1 = std::max(c.x1, q.x);
+                c.y0 = std::min(c.y0, q.y); c.y1 = std::max(c.y1, q.y);
             }
         }
+        touched.n = tn;
         c.count = points.size() - c.first;
         contours.push_back(c);
     }
@@ -457,7 +528,7 @@ class BitScanner {
     uint32_t *lab_;
 
   public:
-    std::vector<Pt> &points;
+    RawBuf<Pt> &points;
     std::vector<Contour> &contours;  // in discovery order (cv2 reports them reversed)
 };
 

@@ -749,7 +749,7 @@ extern "C" int sv_find_grid_corners_bits_batch(const uint32_t *bits, int n, int 
 // is rewritten iff the old or the new frame has a word in it.  A chunk of a row's last group may reach past the row: it lands, as
 // zeros (mask bits beyond the row are validated to be clear), in pad words and in the first words of the next row(s), which are
 // processed after it, and the scratch image has 64 words of slack behind its last row.  prev is replaced by the new masks.
-__attribute__((target("avx512f"))) static void sparse_expand_avx512(const uint64_t *masks, uint64_t *prev, const uint32_t *val, int H, int gpr, uint32_t *row0,
+__attribute__((target("avx512f,popcnt"))) static void sparse_expand_avx512(const uint64_t *masks, uint64_t *prev, const uint32_t *val, int H, int gpr, uint32_t *row0,
                                                                    int stride)
 {
     for (int y = 0; y < H; y++) {
@@ -758,15 +758,36 @@ __attribute__((target("avx512f"))) static void sparse_expand_avx512(const uint64
             const uint64_t m = masks[(size_t)y * gpr + g], either = m | prev[(size_t)y * gpr + g];
             prev[(size_t)y * gpr + g] = m;
             if (!either) continue;
-            for (int j = 0; j < 4; j++) {
-                if (!((either >> (16 * j)) & 0xFFFF)) continue;
-                const __mmask16 mj = (__mmask16)(m >> (16 * j));
-                _mm512_storeu_si512(row + 64 * g + 16 * j, _mm512_maskz_expandloadu_epi32(mj, val));
-                val += __builtin_popcount((unsigned)mj);
-            }
+            // where each chunk's values start comes from prefix counts of the mask, not from the chunk before it: the four expand-loads
+            // of a group are independent, and the chain from group to group is one popcount
+            const uint32_t *v0 = val, *v1 = v0 + __builtin_popcountll(m & 0xFFFFull), *v2 = v0 + __builtin_popcountll(m & 0xFFFFFFFFull),
+                           *v3 = v0 + __builtin_popcountll(m & 0xFFFFFFFFFFFFull);
+            val += __builtin_popcountll(m);
+            uint32_t *d = row + 64 * g;
+            if (either & 0xFFFFull) _mm512_storeu_si512(d, _mm512_maskz_expandloadu_epi32((__mmask16)m, v0));
+            if (either & 0xFFFF0000ull) _mm512_storeu_si512(d + 16, _mm512_maskz_expandloadu_epi32((__mmask16)(m >> 16), v1));
+            if (either & 0xFFFF00000000ull) _mm512_storeu_si512(d + 32, _mm512_maskz_expandloadu_epi32((__mmask16)(m >> 32), v2));
+            if (either & 0xFFFF000000000000ull) _mm512_storeu_si512(d + 48, _mm512_maskz_expandloadu_epi32((__mmask16)(m >> 48), v3));
         }
     }
 }
+
+// number of values a record's row masks announce, or -1 if a mask has a bit beyond the last word of its row.  Compiled twice: built
+// without -mpopcnt the popcount is fifteen instructions, and this loop runs over every mask of every frame.
+__attribute__((always_inline)) static inline long count_record_values(const uint64_t *masks, int H, int wpr)
+{
+    const int gpr = (wpr + 63) / 64, tail = wpr & 63;            // tail: valid bits of a row's last mask word (0 = all 64)
+    const uint64_t tail_bad = tail ? ~0ull << tail : 0ull;
+    long total = 0;
+    uint64_t bad = 0;
+    for (int y = 0; y < H; y++) {
+        for (int g = 0; g < gpr; g++) total += __builtin_popcountll(masks[(size_t)y * gpr + g]);
+        bad |= masks[(size_t)y * gpr + gpr - 1] & tail_bad;
+    }
+    return bad ? -1 : total;
+}
+__attribute__((target("popcnt"))) static long count_record_values_popcnt(const uint64_t *masks, int H, int wpr) { return count_record_values(masks, H, wpr); }
+static long count_record_values_generic(const uint64_t *masks, int H, int wpr) { return count_record_values(masks, H, wpr); }
 
 // sparse record (include/sudoku_vision_hip.h, sv_pack_sparse_bits) -> dense bit image.  The record is validated before anything is
 // written from it (it crosses PCIe and may be stale, torn or built for another shape): 1 = expanded, 0 = the record overflowed its
@@ -783,16 +804,9 @@ static int sparse_expand(const uint8_t *record, long avail, int H, int W, uint32
     if (head[0] > head[1]) return 0;
     const uint64_t *masks = reinterpret_cast<const uint64_t *>(record + 8);
     const uint32_t *val = reinterpret_cast<const uint32_t *>(record + head_bytes);
-    const int tail = wpr & 63;                                   // valid bits of a row's last mask word (0 = all 64)
-    const uint64_t tail_bad = tail ? ~0ull << tail : 0ull;
-    size_t total = 0;
-    for (int y = 0; y < H; y++)
-        for (int g = 0; g < gpr; g++) {
-            const uint64_t m = masks[(size_t)y * gpr + g];
-            if (g == gpr - 1 && (m & tail_bad)) return -1;
-            total += (size_t)__builtin_popcountll(m);
-        }
-    if (total != head[0]) return -1;
+    static const bool has_popcnt = __builtin_cpu_supports("popcnt");
+    const long total = has_popcnt ? count_record_values_popcnt(masks, H, wpr) : count_record_values_generic(masks, H, wpr);
+    if (total < 0 || (size_t)total != head[0]) return -1;
     if (scratch) {                                               // the search's padded per-thread image, row masks taken over as they are
         static const bool vec = __builtin_cpu_supports("avx512f");
         scratch->begin(H, W, vec);

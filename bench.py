@@ -249,9 +249,8 @@ def main():
     if not args.no_e2e:
         from sudoku_vision_amd.pipeline import FramePipeline, host_cpu_budget
         # the box's CPU share is 16 cores per GPU, enforced as a cgroup quota: stay two under it (this thread + the HIP runtime's)
-        budget = host_cpu_budget()
-        if budget > 16 * world:                      # no quota (or one far above the per-GPU share): split the host evenly over the ranks
-            budget //= world
+        # (the ranks of one node are children of one launcher: they share its cgroup, hence its quota, and the host's CPUs)
+        budget = host_cpu_budget() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         host_threads = max(1, min(16, budget) - 2)
         chunk = args.chunk or next(c for c in (256, 128, 64, 32, 16, 8, 4, 2, 1) if n % c == 0)
         kw = {"depth": args.depth} if args.depth else {}

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
     //   * A operands flow through a RING-slot register ring, one ds_read_b128 per slot, PF taps ahead of their MFMAs, across tile
     //     boundaries (the tile loop is fully unrolled: all ring indices are static and the lgkmcnt waits are counted exactly);
     //   * all three partial products of a channel tile go into ONE accumulator (f32 either way), double-buffered by tile parity;
-    //     the epilogue of tile j-1 (2x2 max, scale + bias, ReLU, store) is nine single instructions in the slots of taps 2-4.
+    //     the epilogue of tile j-1 (2x2 max, scale + bias, ReLU, hi/lo split, two stores) is 18 single instructions in the slots of taps 2-7.
     constexpr int PF = 5, RING = 6;
     uint4 ring_h[RING], ring_l[RING];
     // per-lane LDS offset of this wave's tile jj (window-in-tile, position dy/dx, k-group of the lane): loop-invariant, 7 registers
@@ -266,7 +266,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
 #define SV_TAP_OFF(tap) (((tap) / 3) * ROW_STRIDE + ((tap) % 3) * POS_STRIDE)
 #define SV_SLOT() __builtin_amdgcn_sched_barrier(0)
     const int ntile = (ablate & 2) ? 0 : (par ? 6 : 7);
-    const unsigned out_off = (32 * np + 2 * c16 + 64 * q + 256 * par) * 4;      // byte offset of (window 4*par + q, channels 32np + 2c16..) in a cell's features
+    // Features leave this kernel already split into f16 pairs, in the order the fc kernels' A operands want them: a cell's 3136 values
+    // (index = 64 window + channel) in groups of 8, each group 16 B of hi parts then 16 B of lo parts.  This lane's two channels of window
+    // 4 (par + 2 jp) + q: group 64 jp + 32 par + 8 q + 4 np + c16 / 4, hi pair at byte 4 (c16 % 4) of it, lo pair 16 B behind.
+    const unsigned out_off = (32 * par + 8 * q + 4 * np + (c16 >> 2)) * 32 + (c16 & 3) * 4;
     unsigned long long dbg_t[4] = {0, 0, 0, 0}, dbg_s = 0;
 #define SV_STAMP(i) do { if (ablate & 16) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); dbg_t[i] += t_ - dbg_s; dbg_s = t_; } } while (0)
     if (ablate & 16) dbg_s = __builtin_amdgcn_s_memtime();
@@ -281,7 +284,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
             ring_l[st % RING] = *(const uint4 *)(ap + SV_TAP_OFF(st) + PLANE_B);
         }
         f32x4 acc[2][2];                                                        // [tile parity][t]
-        float m0 = 0.f, m1 = 0.f;
+        float m0 = 0.f, m1 = 0.f, t0 = 0.f, t1 = 0.f;
+        unsigned h0 = 0, h1 = 0, hp = 0, lp = 0;
         // one single-instruction piece of the epilogue of the tile whose sums sit in accumulator set `set` (tile index jp of this wave)
         auto epilogue = [&](int piece, int jp, int set) {
             const f32x4 &v0 = acc[set][0], &v1 = acc[set][1];
@@ -294,8 +298,20 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
             case 5: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(m1) : "s"(scale_inv), "v"(bias2_1)); break;
             case 6: asm volatile("v_max_f32 %0, 0, %0" : "+v"(m0)); break;
             case 7: asm volatile("v_max_f32 %0, 0, %0" : "+v"(m1)); break;
-            default:                                                            // rows 4q..4q+3 = the 4 positions of window 4*(par + 2jp) + q
-                if (jp < 6 || q == 0) *(f32x2 *)(fcell + jp * 2048 + out_off) = (f32x2){m0, m1};
+            // split_h2 of both values, one instruction per slot: hi = f16(m), lo = f16(m - f32(hi))
+            case 8: asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(h0) : "v"(m0)); break;
+            case 9: asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(h1) : "v"(m1)); break;
+            case 10: asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(t0) : "v"(h0)); break;
+            case 11: asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(t1) : "v"(h1)); break;
+            case 12: asm volatile("v_sub_f32 %0, %1, %0" : "+v"(t0) : "v"(m0)); break;
+            case 13: asm volatile("v_sub_f32 %0, %1, %0" : "+v"(t1) : "v"(m1)); break;
+            case 14: asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(hp) : "v"(h0), "v"(h1)); break;
+            case 15: asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(t0), "v"(t1)); break;
+            case 16:                                                            // rows 4q..4q+3 = the 4 positions of window 4*(par + 2jp) + q
+                if (jp < 6 || q == 0) *(unsigned *)(fcell + jp * 2048 + out_off) = hp;
+                break;
+            default:
+                if (jp < 6 || q == 0) *(unsigned *)(fcell + jp * 2048 + out_off + 16) = lp;
             }
         };
         // 13 M tiles of 4 pooling windows; this wave takes tiles par, par+2, ... for its 32 channels
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
                 const h8 ah = __builtin_bit_cast(h8, ring_h[st % RING]), al = __builtin_bit_cast(h8, ring_l[st % RING]);
                 const h8 bh0 = __builtin_bit_cast(h8, breg[tap][0][0]), bl0 = __builtin_bit_cast(h8, breg[tap][0][1]);
                 const h8 bh1 = __builtin_bit_cast(h8, breg[tap][1][0]), bl1 = __builtin_bit_cast(h8, breg[tap][1][1]);
-                const int e0 = (jj > 0 && tap >= 2 && tap <= 4) ? 3 * (tap - 2) : -1;   // epilogue pieces e0, e0+1, e0+2 in this tap
+                const int e0 = (jj > 0 && tap >= 2 && tap <= 7) ? 3 * (tap - 2) : -1;   // epilogue pieces e0, e0+1, e0+2 in this tap
                 // slot 1
                 SV_SLOT();
                 if (tap == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[set][0]) : "v"(ah), "v"(bh0));
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
         if (ntile > 0) {
             asm volatile("s_nop 15\n\ts_nop 15");                              // the last tile's accumulators: MFMA -> VALU read distance
 #pragma unroll
-            for (int piece = 0; piece < 9; piece++) epilogue(piece, ntile - 1, (ntile - 1) & 1);
+            for (int piece = 0; piece < 18; piece++) epilogue(piece, ntile - 1, (ntile - 1) & 1);
         }
         SV_STAMP(2);
         __syncthreads();                                                        // (B_{k+1}) / (C)
@@ -385,10 +401,11 @@ __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__
     const long cell0 = (long)blockIdx.x * 64 + wave * 16;
     long crow = cell0 + r;
     if (crow >= B) crow = B - 1;
-    // K is permuted so that a lane's operands of the SPS = 2 steps of a stage are 16 consecutive floats (k-slot (q, j) of step
-    // 2S + ss = feature 64S + 16q + 8ss + j; the weight image is packed to match): the four q-lanes of a row read 256
-    // contiguous bytes per stage instead of four 32-byte pieces per step
-    const f32x4 *ap = (const f32x4 *)(feat + crow * FEAT + 16 * q);    // stage S: + 16*S float4
+    // K is permuted so that a lane's operands of the SPS = 2 steps of a stage are 64 consecutive bytes (k-slot (q, j) of step
+    // 2S + ss = feature 64S + 16q + 8ss + j; the weight image is packed to match; k_conv_features_h2 writes the features as f16
+    // pairs, group of 8 by group of 8: 16 B of hi parts, 16 B of lo parts): the four q-lanes of a row read 256 contiguous bytes
+    // per stage, and what arrives are the MFMA operands themselves
+    const uint4 *ap = (const uint4 *)(feat + crow * FEAT + 16 * q);     // stage S: + 16*S uint4; [2 ss] = hi, [2 ss + 1] = lo
 
     for (int i = tid; i < 1280; i += 256) w2s[i >> 7][i & 127] = w2[i];
 
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__
     for (int t = 0; t < 8; t++) { acc_h[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc_l[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     uint4 wreg[WPT];
-    f32x4 areg[SPS][2];
+    uint4 areg[SPS][2];
 #pragma unroll
     for (int j = 0; j < WPT; j++) wreg[j] = w1img[256 * j + tid];
 #pragma unroll
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__
 
     for (int st = 0; st < NSTAGE; st++) {
         const int cur = st & 1;
-        f32x4 a[SPS][2];
+        uint4 a[SPS][2];
 #pragma unroll
         for (int s = 0; s < SPS; s++) { a[s][0] = areg[s][0]; a[s][1] = areg[s][1]; }
         if (st + 1 < NSTAGE) {                                        // next stage: global -> registers while this one computes
@@ -420,10 +437,7 @@ __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__
         __builtin_amdgcn_sched_barrier(0);     // (the compiler otherwise sinks these loads to their use at the end of the stage, exposing their latency)
 #pragma unroll
         for (int s = 0; s < SPS; s++) {
-            _Float16 h[8], l[8];
-#pragma unroll
-            for (int e = 0; e < 4; e++) { split_h2(a[s][0][e], h[e], l[e]); split_h2(a[s][1][e], h[4 + e], l[4 + e]); }
-            const h8 ah = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]}, al = {l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
+            const h8 ah = __builtin_bit_cast(h8, a[s][0]), al = __builtin_bit_cast(h8, a[s][1]);
 #pragma unroll
             for (int t = 0; t < 8; t++) {
                 const h8 bh = __builtin_bit_cast(h8, wt[cur][((s * 8 + t) * 2 + 0) * 64 + lane]);
@@ -473,6 +487,180 @@ __global__ __launch_bounds__(256, 2) void k_fc_head_h2(const float *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_fc_head_h2p: the same arithmetic for large batches, one 768-thread workgroup per CU that streams the 1.6 MB weight image
+// ONCE for all of its cells (k_fc_head_h2 streams it once per 64 cells: 324 times for 256 frames, 0.52 GB through the L2s).
+// 12 waves = 6 M tiles (96 cells per pass) x 2 N halves; 3 waves per SIMD.
+// What bounds an fc kernel of this shape is not the MFMA pipe (a quarter busy), the LDS or the L2s but the texture addresser:
+// a wave-load of MFMA A fragments straight from the features touches 64 different 16-byte pieces in 32 lines and takes the
+// TA ~55 cycles, and the waves queue up behind it in program order (tools/ubench_fc_read.hip: 62 us for the 260 MB read that
+// way, 40 us with 16 adjacent lanes reading 256 contiguous bytes).  So BOTH operands go global -> LDS directly
+// (global_load_lds_dwordx4, inline asm: hipcc would guard every ds_read after one with vmcnt(0)):
+//   * weights: 32 pieces of 1 KB per 32-KB stage (waves 0-7, four each), ring of two stages, one in flight (L2 hits);
+//   * features: 24 pieces per stage, each 4 rows x 256 B with lane-contiguous sources (two per wave), ring of three 24-KB
+//     stages, two in flight (HBM).  The image is row-major, [96 rows][16 units of 16 B]; unit u of row r sits in slot
+//     u ^ g(r), g(r) = (r & 3) << 2 | (r >> 2) & 3 -- the DMA cannot scatter, so the permutation is on the source address --
+//     which makes the 16 lanes of every ds_read_b128 lane group of an A-fragment fetch hit 16 different bank slots.
+// One counted wait and one raw barrier per stage: at the top of stage s a wave waits until only its two feature pieces of
+// stage s + 1 are in flight (s_waitcnt vmcnt(2): its weight pieces of stage s, issued after the features of s and before
+// those of s + 1, have landed), the barrier makes everybody's pieces visible and frees the slots that stage s - 1 read, and
+// the pieces of weight stage s + 1 and feature stage s + 2 are issued into them.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FCP_WAVES = 12, FCP_MT = 6, FCP_CELLS = 16 * FCP_MT, FCP_NSTAGE = 49;
+constexpr int FCP_W_STAGE = 32768, FCP_A_STAGE = FCP_CELLS * 256, FCP_OFF_A = 2 * FCP_W_STAGE;
+constexpr int FCP_HS_LD = 129;
+
+// one LDS-DMA piece: 64 lanes x 16 B from the lanes' own addresses to lds_dst + 16 * lane (M0 carries the LDS byte address)
+__device__ __forceinline__ void fcp_glds(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(64 * FCP_WAVES, 1) void k_fc_head_h2p(const float *__restrict__ feat, long B, long per, const uint4 *__restrict__ w1img,
+                                                                  const float *__restrict__ b1, float scale_inv, const float *__restrict__ w2,
+                                                                  const float *__restrict__ b2, float *__restrict__ logits, u8 *__restrict__ digits,
+                                                                  float *__restrict__ conf, const int *__restrict__ run_if_clear)
+{
+    if (run_if_clear && *run_if_clear != 0) return;
+    // one LDS object: [2 weight stages (the hidden activations alias them after the K loop)][3 feature stages][w2][logits]
+    constexpr int OFF_W2 = FCP_OFF_A + 3 * FCP_A_STAGE, OFF_LG = OFF_W2 + 10 * 128 * 4, LDS_B = OFF_LG + FCP_MT * 16 * 12 * 4;
+    static_assert(FCP_CELLS * FCP_HS_LD * 4 <= 2 * FCP_W_STAGE, "the hidden activations alias the weight ring");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_B];
+    float(*hs)[FCP_HS_LD] = (float(*)[FCP_HS_LD])lds;                                 // [96][129] floats = 49.5 KB
+    float(*w2s)[128] = (float(*)[128])(lds + OFF_W2);
+    float(*lg)[16][12] = (float(*)[16][12])(lds + OFF_LG);
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int mt = wave % FCP_MT, nh = wave / FCP_MT;                                  // M tile, N half (hidden units 64 nh ..)
+    const bool loader = wave < 8;
+    for (int i = tid; i < 1280; i += 64 * FCP_WAVES) w2s[i >> 7][i & 127] = w2[i];
+
+    // this lane's A fragments in a feature stage: row 16 mt + r; (step ss, part) = unit 4 q + 2 ss + part, in slot unit ^ g(r)
+    const unsigned g_r = ((unsigned)(r & 3) << 2) | (unsigned)(r >> 2);
+    unsigned a_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) a_off[c] = FCP_OFF_A + (16 * mt + r) * 256 + (((unsigned)(4 * q + c)) ^ g_r) * 16;
+    // this lane's share of the wave's two feature pieces: row 8 wave + 4 i + lane / 16 of the pass, slot lane % 16 -> unit slot ^ g(row)
+    const int prow = 8 * wave + (lane >> 4), pslot = lane & 15;
+
+    const long c_begin = (long)blockIdx.x * per, c_end = c_begin + per < B ? c_begin + per : B;
+    for (long base = c_begin; base < c_end; base += FCP_CELLS) {
+        const long cell0 = base + 16 * mt;
+        const bool tile_live = cell0 < c_end;                            // (wave-uniform) an M tile with no cell does no arithmetic
+        const unsigned char *asrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int rl = prow + 4 * i;
+            long row = base + rl;
+            if (row >= c_end) row = c_end - 1;                                         // rows past the end: a valid address, results dropped
+            const unsigned gr = ((unsigned)(rl & 3) << 2) | ((unsigned)(rl >> 2) & 3u);
+            asrc[i] = (const unsigned char *)feat + row * (FEAT * 4) + (((unsigned)pslot) ^ gr) * 16;
+        }
+        const uint4 *wp = w1img + (wave & 7) * 4 * 64 + lane;                          // this wave's 4 pieces of a weight stage
+        auto issue_w = [&](int st) {
+            if (loader) {
+                const unsigned dst = lds_base + (st & 1) * FCP_W_STAGE + (wave & 7) * 4096;
+#pragma unroll
+                for (int j = 0; j < 4; j++) fcp_glds(wp + (long)st * 2048 + 64 * j, dst + 1024 * j);
+            }
+        };
+        auto issue_a = [&](int st) {
+            const unsigned dst = lds_base + FCP_OFF_A + (st % 3) * FCP_A_STAGE + 2 * wave * 1024;
+#pragma unroll
+            for (int i = 0; i < 2; i++) fcp_glds(asrc[i] + 256 * st, dst + 1024 * i);
+        };
+        f32x4 acc_h[4], acc_l[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { acc_h[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc_l[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        issue_w(0);
+        issue_a(0);
+        issue_a(1);
+
+        // The stage's eight (step, N tile) pairs are a pipeline of their own: the hi/lo B fragments of pairs i + BD, i + BD + 1 are read from
+        // the LDS while the six MFMAs of pairs i, i + 1 issue (two N tiles at a time: no MFMA reads the result of the one before it).
+        auto compute = [&](int st) {
+            constexpr int BD = 4;
+            const unsigned char *wt = lds + (st & 1) * FCP_W_STAGE + lane * 16, *at = lds + (st % 3) * FCP_A_STAGE;
+            uint4 fa[4], fb[8][2];
+#pragma unroll
+            for (int c = 0; c < 4; c++) fa[c] = *(const uint4 *)(at + a_off[c]);
+            auto rd = [&](int i) {
+                const int sstep = i >> 2, t = i & 3;
+                fb[i][0] = *(const uint4 *)(wt + ((sstep * 8 + 4 * nh + t) * 2 + 0) * 1024);
+                fb[i][1] = *(const uint4 *)(wt + ((sstep * 8 + 4 * nh + t) * 2 + 1) * 1024);
+            };
+#pragma unroll
+            for (int i = 0; i < BD; i++) rd(i);
+            __builtin_amdgcn_sched_barrier(0);
+            const h8 ah[2] = {__builtin_bit_cast(h8, fa[0]), __builtin_bit_cast(h8, fa[2])}, al[2] = {__builtin_bit_cast(h8, fa[1]), __builtin_bit_cast(h8, fa[3])};
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                if (i + BD < 8) { rd(i + BD); rd(i + BD + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const int sstep = i >> 2, t = i & 3;
+                const h8 bh0 = __builtin_bit_cast(h8, fb[i][0]), bl0 = __builtin_bit_cast(h8, fb[i][1]);
+                const h8 bh1 = __builtin_bit_cast(h8, fb[i + 1][0]), bl1 = __builtin_bit_cast(h8, fb[i + 1][1]);
+                acc_h[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sstep], bh0, acc_h[t], 0, 0, 0);
+                acc_h[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sstep], bh1, acc_h[t + 1], 0, 0, 0);
+                acc_l[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sstep], bl0, acc_l[t], 0, 0, 0);
+                acc_l[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[sstep], bl1, acc_l[t + 1], 0, 0, 0);
+                acc_l[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[sstep], bh0, acc_l[t], 0, 0, 0);
+                acc_l[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[sstep], bh1, acc_l[t + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int st = 0; st < FCP_NSTAGE; st++) {
+            if (st + 1 < FCP_NSTAGE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (st + 1 < FCP_NSTAGE) issue_w(st + 1);
+            if (st + 2 < FCP_NSTAGE) issue_a(st + 2);
+            if (tile_live) compute(st);
+        }
+        __syncthreads();                                                                // everybody is done reading the rings: hs may overwrite them
+
+        // acc[t][reg]: cell row 4q + reg of the wave's M tile, hidden unit 64 nh + 16 t + r
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float bias = b1[64 * nh + 16 * t + r];
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++)
+                hs[16 * mt + 4 * q + reg][64 * nh + 16 * t + r] = fmaxf((acc_h[t][reg] + acc_l[t][reg]) * scale_inv + bias, 0.f);
+        }
+        __syncthreads();
+        if (nh == 0) {
+            for (int jj = 0; jj < 3; jj++) {                                            // fc2: lane (cell r, class group q) -> classes q, q+4, q+8
+                const int j = q + 4 * jj;
+                if (j < 10) {
+                    float s = b2[j];
+                    for (int n = 0; n < 128; n++) s = __builtin_fmaf(hs[16 * mt + r][n], w2s[j][n], s);
+                    lg[mt][r][j] = s;
+                    if (cell0 + r < c_end) logits[(cell0 + r) * 10 + j] = s;
+                }
+            }
+        }
+        __syncthreads();
+        if (nh == 0 && q == 0 && cell0 + r < c_end && (digits || conf)) {
+            float best = lg[mt][r][0];
+            int arg = 0;
+            for (int j = 1; j < 10; j++)
+                if (lg[mt][r][j] > best) { best = lg[mt][r][j]; arg = j; }
+            if (digits) digits[cell0 + r] = (u8)arg;
+            if (conf) {
+                float den = 0.f;
+                for (int j = 0; j < 10; j++) den += expf(lg[mt][r][j] - best);
+                conf[cell0 + r] = 1.0f / den;
+            }
+        }
+        __syncthreads();                                                                // hs / lg are free again before the next pass refills the rings
+    }
+}
+
 }  // namespace
 
 #ifdef SV_DEV
@@ -503,6 +691,14 @@ int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *
 #undef SV_ABLATE_ARG
     SV_LAUNCH_CHECK("k_conv_features_h2");
     sv_time_scope ts(ctx, SVK_FC_HEAD, s);
+    if ((B + 63) / 64 > (long)ctx->num_cus) {
+        // more 64-cell workgroups than CUs: one workgroup per CU, each streaming the weight image once for its share of the cells
+        const long per = (B + ctx->num_cus - 1) / ctx->num_cus;
+        hipLaunchKernelGGL(k_fc_head_h2p, dim3((unsigned)((B + per - 1) / per)), dim3(64 * FCP_WAVES), 0, s, ctx->features, B, per, (const uint4 *)w.fc1_h2, w.fc1_b,
+                           w.fc1_h2_scale_inv, w.fc2_w, w.fc2_b, logits, digits, conf, run_if_clear);
+        SV_LAUNCH_CHECK("k_fc_head_h2p");
+        return SV_OK;
+    }
     hipLaunchKernelGGL(k_fc_head_h2, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, ctx->features, B, (const uint4 *)w.fc1_h2, w.fc1_b, w.fc1_h2_scale_inv,
                        w.fc2_w, w.fc2_b, logits, digits, conf, run_if_clear);
     SV_LAUNCH_CHECK("k_fc_head_h2");

@@ -555,6 +555,21 @@ def test_cnn_large_batch_frame_kernel(ctx, golden_dir):
     _check_cnn(ctx, sd, cells)
 
 
+@pytest.mark.parametrize("B", [81 * 256, 81 * 256 + 37, 64 * 256 + 1, 96 * 256 + 500])
+def test_cnn_batches_of_the_per_cu_fc_kernel(ctx, golden_dir, B):
+    """More 64-cell tiles than CUs: the fc head runs as k_fc_head_h2p (one workgroup per CU, the weight image streamed once, 96 cells per
+    pass).  The bench's batch (256 frames), a ragged one, the smallest that switches over, and one that needs a second pass per workgroup;
+    every cell against the oracle, trained weights (digit indices exact) and random weights."""
+    g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
+    sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
+    rs = np.random.RandomState(B % 1000)
+    cells = rs.randint(0, 256, (B, 28, 28)).astype(np.uint8)
+    cells[::3] = np.clip(cells[::3].astype(int) // 4 + 150, 0, 255).astype(np.uint8)
+    _check_cnn(ctx, sd, cells)
+    if B == 81 * 256 + 37:
+        _check_cnn(ctx, cnn_oracle.random_state_dict(77), cells)
+
+
 @pytest.mark.parametrize("H,W", [(3648, 2736), (123, 1000), (64, 244)])
 def test_preprocess_other_resolutions(ctx, H, W):
     """The reference's test photos are 2736x3648 portrait; plus widths whose last 240-column strip is partial."""

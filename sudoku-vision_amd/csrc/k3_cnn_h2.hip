@@ -548,8 +548,8 @@ __global__ __launch_bounds__(64 * FCP_WAVES, 1) void k_fc_head_h2p(const float *
     // this lane's share of the wave's two feature pieces: row 8 wave + 4 i + lane / 16 of the pass, slot lane % 16 -> unit slot ^ g(row)
     const int prow = 8 * wave + (lane >> 4), pslot = lane & 15;
 
-    const long c_begin = (long)blockIdx.x * per, c_end = c_begin + per < B ? c_begin + per : B;
-    for (long base = c_begin; base < c_end; base += FCP_CELLS) {
+    const long base = (long)blockIdx.x * per, c_end = base + per < B ? base + per : B;       // per <= 96: one pass (svk_cnn_forward_h2)
+    {
         const long cell0 = base + 16 * mt;
         const bool tile_live = cell0 < c_end;                            // (wave-uniform) an M tile with no cell does no arithmetic
         const unsigned char *asrc[2];
@@ -657,7 +657,6 @@ __global__ __launch_bounds__(64 * FCP_WAVES, 1) void k_fc_head_h2p(const float *
                 conf[cell0 + r] = 1.0f / den;
             }
         }
-        __syncthreads();                                                                // hs / lg are free again before the next pass refills the rings
     }
 }
 
@@ -691,9 +690,11 @@ int svk_cnn_forward_h2(sv_ctx *ctx, const void *x, bool x_is_u8, long B, float *
 #undef SV_ABLATE_ARG
     SV_LAUNCH_CHECK("k_conv_features_h2");
     sv_time_scope ts(ctx, SVK_FC_HEAD, s);
-    if ((B + 63) / 64 > (long)ctx->num_cus) {
-        // more 64-cell workgroups than CUs: one workgroup per CU, each streaming the weight image once for its share of the cells
-        const long per = (B + ctx->num_cus - 1) / ctx->num_cus;
+    // One workgroup per CU and one pass over the weight image as long as a CU's share of the cells fits a pass (96): faster than k_fc_head_h2 at
+    // every such size (81 cells: 0.040 against 0.059 ms; 20,736: 0.069 against 0.094; tools/dev/fc_sweep.py).  Beyond that the share would take a
+    // second full pass for a few cells, and two co-resident 64-cell workgroups per CU do better (32,768 cells: 0.115 against 0.136 ms).
+    const long per = std::max<long>(16, (B + ctx->num_cus - 1) / ctx->num_cus);
+    if (per <= FCP_CELLS) {
         hipLaunchKernelGGL(k_fc_head_h2p, dim3((unsigned)((B + per - 1) / per)), dim3(64 * FCP_WAVES), 0, s, ctx->features, B, per, (const uint4 *)w.fc1_h2, w.fc1_b,
                            w.fc1_h2_scale_inv, w.fc2_w, w.fc2_b, logits, digits, conf, run_if_clear);
         SV_LAUNCH_CHECK("k_fc_head_h2p");

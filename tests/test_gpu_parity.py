@@ -555,11 +555,12 @@ def test_cnn_large_batch_frame_kernel(ctx, golden_dir):
     _check_cnn(ctx, sd, cells)
 
 
-@pytest.mark.parametrize("B", [81 * 256, 81 * 256 + 37, 64 * 256 + 1, 96 * 256 + 500])
+@pytest.mark.parametrize("B", [81 * 256, 81 * 256 + 37, 41 * 256 + 5, 96 * 256, 96 * 256 + 1, 128 * 256])
 def test_cnn_batches_of_the_per_cu_fc_kernel(ctx, golden_dir, B):
-    """More 64-cell tiles than CUs: the fc head runs as k_fc_head_h2p (one workgroup per CU, the weight image streamed once, 96 cells per
-    pass).  The bench's batch (256 frames), a ragged one, the smallest that switches over, and one that needs a second pass per workgroup;
-    every cell against the oracle, trained weights (digit indices exact) and random weights."""
+    """The fc head runs as k_fc_head_h2p (one workgroup per CU, the weight image streamed once, operands by LDS-DMA) while a CU's share of the
+    cells fits one 96-cell pass, as k_fc_head_h2 beyond: the bench's batch (256 frames: 81 cells per CU, a sixth M tile with one row), a ragged
+    one, a mid-size one (three M tiles per workgroup), the largest one-pass batch, the first past it and 512 frames; every cell against the
+    oracle, trained weights (digit indices exact) and random weights.  (The small batches of the other CNN tests run k_fc_head_h2p too.)"""
     g2 = np.load(os.path.join(golden_dir, "cnn_coreml_fp16.npz"))
     sd = {k: torch.from_numpy(g2[k.replace(".", "_")].astype(np.float32)) for k in cnn_oracle.KEYS}
     rs = np.random.RandomState(B % 1000)

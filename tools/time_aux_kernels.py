@@ -1,7 +1,8 @@
 import sys, os, torch, numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'oracle')
-import sudoku_vision_amd as sva, cnn_oracle
-ctx = sva.default_context(); ctx.load_state_dict(cnn_oracle.random_state_dict(1)); ctx.reserve(20736)
+sys.path.insert(0, os.getcwd())
+import sudoku_vision_amd as sva
+from sudoku_vision_amd.synth import random_state_dict
+ctx = sva.default_context(); ctx.load_state_dict(random_state_dict(1)); ctx.reserve(20736)
 cells = torch.randint(0, 256, (20736, 28, 28), dtype=torch.uint8, device='cuda')
 def t(fn, n=10):
     fn(); torch.cuda.synchronize()

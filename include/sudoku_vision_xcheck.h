@@ -1,7 +1,7 @@
 /*
  * sudoku_vision_xcheck.h -- the extra entry points of libsudokuvision_xcheck.so, a TEST-ONLY superset build of libsudokuvision_hip.so
  * (csrc/Makefile: the product's sources with -DSV_XCHECK + csrc/k1_threshold_mm.hip).  It carries independent second implementations of
- * two stages so that tests/ and tools/fuzz_gpu.py can compare the product's kernels with them on the GPU; the product library does not
+ * two stages so that tests/ and tests/fuzz_gpu.py can compare the product's kernels with them on the GPU; the product library does not
  * contain them and no Python module of the sudoku-vision_amd package loads this one.  Everything in sudoku_vision_hip.h is exported here as well.
  */
 #ifndef SUDOKU_VISION_XCHECK_H

@@ -49,6 +49,13 @@ __device__ __forceinline__ u64 fill_runs(u64 f, u64 fr, u64 g)
 }
 
 constexpr int T = 64, MAX_IT = 96;
+// The first PLAIN_FIRST iterations of a fill stay in the row orientation: most tiles hold nothing but specks a few rows deep, whose fill
+// needs that many steps across rows and no transposition (two to three 64x64 transposes cost more than the iterations they save there);
+// only a tile still changing after them -- something tall, a grid line -- starts alternating.  Any iteration that changes nothing is a
+// fixed point of both orientations (each also steps across its slow direction), so the result is the same for every PLAIN_FIRST.
+#ifndef PLAIN_FIRST
+#define PLAIN_FIRST 2
+#endif
 
 // 64x64 bit transpose across the wave: lane r holds row r (bit c = column c) -> lane c holds column c (bit r).
 // Scale 32: lanes r < 32 exchange their high word with the low word of lane r + 32 (v_permlane32_swap).  Scale k < 32, per 32-bit
@@ -102,6 +109,7 @@ __device__ __forceinline__ u64 ring_connected(u64 f, int lane)
         const bool changed = g2 != g;
         g = g2;
         if (!__any(changed)) { converged = true; break; }
+        if (it < PLAIN_FIRST - 1) continue;                               // (see PLAIN_FIRST)
         if (!have_ft) { ft = transpose64(f, lane); ftr = __brevll(ft); have_ft = true; }
         g = transpose64(g, lane);
         transposed = !transposed;
@@ -196,6 +204,40 @@ __global__ __launch_bounds__(256) void k_despeckle_bits(u32 *__restrict__ bits, 
         if (keep == f[t]) continue;
         if (ok0[t] && (u32)keep != (u32)f[t]) row[k0[t]] = (u32)keep;
         if (ok1[t] && (u32)(keep >> 32) != (u32)(f[t] >> 32)) row[k0[t] + 1] = (u32)(keep >> 32);
+    }
+}
+
+// The same, one 512-thread workgroup per band of 64 rows (all tiles of a tile row): the band is read row by row -- a wave-load is a
+// row's 4 W/32 contiguous bytes -- into the LDS (row pitch odd: lane = row reads are conflict-free), and the waves take their tiles'
+// two words per row from there.  With lane = row loads straight from memory (k_despeckle_bits) every lane of a wave-load is its own
+// 4-byte access in its own line and the texture addresser, not the fill, paces the kernel (tools/dev/despeckle_time.py with the fill
+// compiled out: 0.07 of the 0.15 ms per 256 frames).
+__global__ __launch_bounds__(512) void k_despeckle_bits_band(u32 *__restrict__ bits, int H, int wpr, int pitch, int ox, int oy, int tiles_x, int tiles_y)
+{
+    extern __shared__ u32 band[];                                          // [T][pitch]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ty = blockIdx.x % tiles_y;
+    const long frame = blockIdx.x / tiles_y;
+    const int y0 = ty * T - oy;
+    u32 *img = bits + frame * H * (long)wpr;
+    for (int r = wave; r < T; r += 8) {
+        const int y = y0 + r;
+        const bool ok = y >= 0 && y < H;
+        for (int k = lane; k < wpr; k += 64) band[r * pitch + k] = ok ? img[(long)y * wpr + k] : 0u;
+    }
+    __syncthreads();
+    const int y = y0 + lane;
+    const bool row_ok = y >= 0 && y < H;
+    u32 *row = img + (long)(row_ok ? y : 0) * wpr;
+    const u32 *brow = band + lane * pitch;
+    for (int tx = wave; tx < tiles_x; tx += 8) {
+        const int k0 = (tx * T - ox) >> 5;                                 // first word of the tile row (-1 for the first tile of the offset grid)
+        const bool ok0 = k0 >= 0 && k0 < wpr, ok1 = k0 + 1 < wpr;
+        const u64 f = (ok0 ? (u64)brow[k0] : 0ull) | (ok1 ? (u64)brow[k0 + 1] << 32 : 0ull);
+        const u64 keep = ring_connected(f, lane);
+        if (keep == f || !row_ok) continue;
+        if (ok0 && (u32)keep != (u32)f) row[k0] = (u32)keep;
+        if (ok1 && (u32)(keep >> 32) != (u32)(f >> 32)) row[k0 + 1] = (u32)(keep >> 32);
     }
 }
 
@@ -303,8 +345,14 @@ int svk_despeckle_bits(uint32_t *bits, int n, int H, int W, hipStream_t s)
     for (int pass = 0; pass < 2; pass++) {
         const int o = pass ? T / 2 : 0;
         const int tiles_x = (W + o + T - 1) / T, tiles_y = (H + o + T - 1) / T;
+        const int wpr = W >> 5, pitch = wpr | 1;
+        if ((size_t)T * pitch * 4 <= 65536) {                             // a band fits the LDS: rows up to 8,160 px wide
+            hipLaunchKernelGGL(k_despeckle_bits_band, dim3((unsigned)(n * tiles_y)), dim3(512), (size_t)T * pitch * 4, s, bits, H, wpr, pitch, o, o, tiles_x, tiles_y);
+            SV_LAUNCH_CHECK("k_despeckle_bits_band");
+            continue;
+        }
         const long ngroups = (long)n * ((tiles_x + TPW - 1) / TPW) * tiles_y;
-        hipLaunchKernelGGL(k_despeckle_bits, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, bits, H, W >> 5, o, o, tiles_x, tiles_y, ngroups);
+        hipLaunchKernelGGL(k_despeckle_bits, dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, bits, H, wpr, o, o, tiles_x, tiles_y, ngroups);
         SV_LAUNCH_CHECK("k_despeckle_bits");
     }
     return SV_OK;

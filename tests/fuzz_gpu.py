@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off differential fuzz of the HIP path against the oracle / Pillow on random shapes (run on a GPU box):
+"""(Not collected by pytest; it lives here because it uses the oracle.)  One-off differential fuzz of the HIP path against the oracle / Pillow on random shapes (run on a GPU box):
 K1 on random H x W noise and structured images, K2 on random quadrilaterals (some partly outside the frame), the JPEG
 front end on random sizes / qualities / sub-samplings.  Prints a summary; exits non-zero on the first mismatch."""
 import io

@@ -370,6 +370,19 @@ def test_despeckle_equals_tile_labelling(ctx):
     assert (got[6] != imgs[6]).any() and (got[1] != imgs[1]).any() and (got[0] != imgs[0]).any()   # something was erased at all
 
 
+@pytest.mark.parametrize("H,W", [(130, 8192), (100, 8160), (70, 64), (200, 96)])
+def test_despeckle_bits_widths(ctx, H, W):
+    """sv_despeckle_bits on widths either side of what one 64-row band holds in the LDS (k_despeckle_bits_band up to 8,160 px, the tile-per-wave
+    kernel beyond), one tile wide, and a width with an odd number of words per row; against the per-tile labelling."""
+    rs = np.random.RandomState(H + W)
+    yy, xx = np.mgrid[:H, :W]
+    img = (rs.uniform(size=(H, W)) < 0.12) | (xx % 97 == 5) | (yy % 45 == 7)
+    bits = torch.from_numpy(np.packbits(img[None], axis=2, bitorder="little").view(np.int32)).cuda()
+    got = np.unpackbits(ctx.despeckle_bits(bits).cpu().numpy().view(np.uint8).reshape(1, H, -1), axis=2, bitorder="little").astype(bool)[0]
+    want = _despeckle_np(img)
+    assert np.array_equal(got, want) and (want != img).any()
+
+
 def test_despeckle_preserves_grid_search(ctx):
     """The despeckle accelerator erases only whole components that sit strictly inside a 64x64 tile, and the host
     corner search returns the same answer on the filtered image (synthetic frames + adversarial blob images)."""

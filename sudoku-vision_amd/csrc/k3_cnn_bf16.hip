@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_features_bf16(const u8 *__restr
 {
     __shared__ __attribute__((aligned(16))) unsigned char c1b[2 * C1B_CELL];
     __shared__ float in_s[2 * IN_CELL];
+    __shared__ float w1s[32 * 9 + 32];        // conv1 weights and biases (see the note at conv1 below)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_features_bf16(const u8 *__restr
 
     for (int i = tid; i < 2 * C1B_CELL / 4; i += 256) ((unsigned *)c1b)[i] = 0;    // zero borders, for good
     for (int i = tid; i < 2 * IN_CELL; i += 256) in_s[i] = 0.f;
+    for (int i = tid; i < 32 * 9 + 32; i += 256) w1s[i] = i < 288 ? w1[i] : b1[i - 288];
     __syncthreads();
 
     const long npairs = (B + 1) / 2;
@@ -100,8 +102,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_features_bf16(const u8 *__restr
 #pragma unroll
                 for (int o = 0; o < 8; o++) {
                     const int oc = wave * 8 + o;
-                    const float *w = w1 + oc * 9;
-                    const float bias = b1[oc];
+                    // The weights come out of the LDS, i.e. in VGPRs: read from global memory they are wave-uniform, hipcc keeps them in SGPRs
+                    // (s_load inside this loop) and feeds them to v_pk_fma_f32 as SGPR-pair operands, and with two waves per SIMD (two
+                    // workgroups per CU) the results then differ from run to run in the last bits of a few per cent of the cells -- with
+                    // scalar FMAs, with one workgroup per CU or with the weights in VGPRs they never do (round 3; the other kernels' packed
+                    // FMAs take their SGPR operands from kernel arguments loaded once, and are bit-exact in every test).
+                    const float *w = w1s + oc * 9;
+                    const float bias = w1s[288 + oc];
                     f32x2 a0 = {bias, bias}, a1 = {bias, bias};
 #pragma unroll
                     for (int ky = 0; ky < 3; ky++)
@@ -216,6 +223,126 @@ __global__ __launch_bounds__(256) void k_fc_head_bf16(const unsigned short *__re
     }
 }
 
+
+// k_fc_head_bf16p: the per-CU form of the fc head (k_fc_head_h2p in k3_cnn_h2.hip has the reasoning and the measurements): one 768-thread
+// workgroup per CU, 12 waves = 6 M tiles x 2 N halves, the weight image streamed once per CU, both operands global -> LDS by DMA, one counted
+// wait and one raw barrier per 64-k stage.  bf16 sizes: a feature row gives 128 B per stage, a DMA piece is 8 rows x 128 B (one per wave, ring of
+// three 12-KB stages), the weight stage is 16 KB (waves 0-7, two pieces each, ring of two).  Feature image in the LDS: [96 rows][8 units of 16 B],
+// unit u of row r in slot u ^ (r >> 1 & 7): two rows share a 256-B bank row, and with that the 16 lanes of a ds_read_b128 lane group hit 16 slots.
+constexpr int BFP_WAVES = 12, BFP_MT = 6, BFP_CELLS = 16 * BFP_MT, BFP_NSTAGE = 49;
+constexpr int BFP_W_STAGE = 16384, BFP_A_STAGE = BFP_CELLS * 128, BFP_OFF_A = 2 * BFP_W_STAGE, BFP_HS_LD = 129;
+
+__device__ __forceinline__ void bfp_glds(const void *gsrc, unsigned lds_dst)          // 64 lanes x 16 B -> lds_dst + 16 * lane
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(64 * BFP_WAVES, 1) void k_fc_head_bf16p(const unsigned short *__restrict__ feat, long B, long per, const uint4 *__restrict__ w1img,
+                                                                    const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                    float *__restrict__ logits, u8 *__restrict__ digits, float *__restrict__ conf)
+{
+    // one LDS object: [2 weight stages][3 feature stages] (the hidden activations alias both after the K loop) [w2][logits]
+    constexpr int RINGS = BFP_OFF_A + 3 * BFP_A_STAGE, HS_B = BFP_CELLS * BFP_HS_LD * 4;
+    constexpr int OFF_W2 = RINGS > HS_B ? RINGS : HS_B, OFF_LG = OFF_W2 + 10 * 128 * 4, LDS_B = OFF_LG + BFP_MT * 16 * 12 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_B];
+    float(*hs)[BFP_HS_LD] = (float(*)[BFP_HS_LD])lds;
+    float(*w2s)[128] = (float(*)[128])(lds + OFF_W2);
+    float(*lg)[16][12] = (float(*)[16][12])(lds + OFF_LG);
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)lds;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int mt = wave % BFP_MT, nh = wave / BFP_MT;
+    const bool loader = wave < 8;
+    for (int i = tid; i < 1280; i += 64 * BFP_WAVES) w2s[i >> 7][i & 127] = w2[i];
+
+    // this lane's A fragments in a feature stage: row 16 mt + r, step ss = unit 4 ss + q, in slot unit ^ (r >> 1 & 7)
+    unsigned a_off[2];
+#pragma unroll
+    for (int ss = 0; ss < 2; ss++) a_off[ss] = BFP_OFF_A + (16 * mt + r) * 128 + (((unsigned)(4 * ss + q)) ^ ((unsigned)(r >> 1) & 7u)) * 16;
+
+    const long base = (long)blockIdx.x * per, c_end = base + per < B ? base + per : B;          // per <= 96: one pass (svk_cnn_forward_bf16)
+    const long cell0 = base + 16 * mt;
+    const bool tile_live = cell0 < c_end;
+    // this lane's share of the wave's feature piece: row 8 wave + lane / 8 of the pass, slot lane % 8 -> unit slot ^ (row >> 1 & 7)
+    const int rl = 8 * wave + (lane >> 3);
+    long srow = base + rl;
+    if (srow >= c_end) srow = c_end - 1;
+    const unsigned char *asrc = (const unsigned char *)(feat + srow * FEAT) + ((((unsigned)lane & 7u) ^ ((unsigned)(rl >> 1) & 7u)) * 16);
+    const uint4 *wp = w1img + (wave & 7) * 2 * 64 + lane;                                       // this wave's 2 pieces of a weight stage
+    auto issue_w = [&](int st) {
+        if (loader) {
+            const unsigned dst = lds_base + (st & 1) * BFP_W_STAGE + (wave & 7) * 2048;
+            bfp_glds(wp + (long)st * 1024, dst);
+            bfp_glds(wp + (long)st * 1024 + 64, dst + 1024);
+        }
+    };
+    auto issue_a = [&](int st) { bfp_glds(asrc + 128 * st, lds_base + BFP_OFF_A + (st % 3) * BFP_A_STAGE + wave * 1024); };
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    issue_w(0);
+    issue_a(0);
+    issue_a(1);
+    for (int st = 0; st < BFP_NSTAGE; st++) {
+        // only this wave's feature piece of stage st + 1 stays in flight: its weight pieces of stage st were issued before it
+        if (st + 1 < BFP_NSTAGE) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < BFP_NSTAGE) issue_w(st + 1);
+        if (st + 2 < BFP_NSTAGE) issue_a(st + 2);
+        if (tile_live) {
+            const unsigned char *wt = lds + (st & 1) * BFP_W_STAGE + lane * 16, *at = lds + (st % 3) * BFP_A_STAGE;
+            uint4 fa[2], fb[2][4];
+#pragma unroll
+            for (int ss = 0; ss < 2; ss++) fa[ss] = *(const uint4 *)(at + a_off[ss]);
+#pragma unroll
+            for (int ss = 0; ss < 2; ss++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) fb[ss][t] = *(const uint4 *)(wt + (ss * 8 + 4 * nh + t) * 1024);
+#pragma unroll
+            for (int ss = 0; ss < 2; ss++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ss]), __builtin_bit_cast(bf16x8, fb[ss][t]), acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                                           // everybody is done reading the rings: hs may overwrite them
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float bias = b1[64 * nh + 16 * t + r];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) hs[16 * mt + 4 * q + reg][64 * nh + 16 * t + r] = fmaxf(acc[t][reg] + bias, 0.f);
+    }
+    __syncthreads();
+    if (nh == 0) {
+        for (int jj = 0; jj < 3; jj++) {
+            const int j = q + 4 * jj;
+            if (j < 10) {
+                float sacc = b2[j];
+                for (int n = 0; n < 128; n++) sacc = __builtin_fmaf(hs[16 * mt + r][n], w2s[j][n], sacc);
+                lg[mt][r][j] = sacc;
+                if (cell0 + r < c_end) logits[(cell0 + r) * 10 + j] = sacc;
+            }
+        }
+    }
+    __syncthreads();
+    if (nh == 0 && q == 0 && cell0 + r < c_end && (digits || conf)) {
+        float best = lg[mt][r][0];
+        int arg = 0;
+        for (int j = 1; j < 10; j++)
+            if (lg[mt][r][j] > best) { best = lg[mt][r][j]; arg = j; }
+        if (digits) digits[cell0 + r] = (u8)arg;
+        if (conf) {
+            float den = 0.f;
+            for (int j = 0; j < 10; j++) den += expf(lg[mt][r][j] - best);
+            conf[cell0 + r] = 1.0f / den;
+        }
+    }
+}
+
 }  // namespace
 
 int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8 *digits, float *conf, hipStream_t s)
@@ -231,6 +358,13 @@ int svk_cnn_forward_bf16(sv_ctx *ctx, const u8 *cells, long B, float *logits, u8
     }
     SV_LAUNCH_CHECK("k_conv_features_bf16");
     sv_time_scope ts(ctx, SVK_FC_HEAD, s);
+    const long per = std::max<long>(16, (B + ctx->num_cus - 1) / ctx->num_cus);               // as in svk_cnn_forward_h2
+    if (per <= BFP_CELLS) {
+        hipLaunchKernelGGL(k_fc_head_bf16p, dim3((unsigned)((B + per - 1) / per)), dim3(64 * BFP_WAVES), 0, s, (const unsigned short *)ctx->features, B, per,
+                           (const uint4 *)w.fc1_bf16, w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
+        SV_LAUNCH_CHECK("k_fc_head_bf16p");
+        return SV_OK;
+    }
     hipLaunchKernelGGL(k_fc_head_bf16, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s, (const unsigned short *)ctx->features, B, (const uint4 *)w.fc1_bf16,
                        w.fc1_b, w.fc2_w, w.fc2_b, logits, digits, conf);
     SV_LAUNCH_CHECK("k_fc_head_bf16");

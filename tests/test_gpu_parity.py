@@ -478,6 +478,29 @@ def test_bf16_configuration_digit_parity(golden_dir):
     c.close()
 
 
+def test_stages_are_deterministic(ctx):
+    """K1 (bytes and bits), the speck filter, the sparse records and K2 give the same bits twice on 64 1080p frames: a launch that fills every
+    CU several times over (what test_cnn_is_deterministic does for K3)."""
+    import sudoku_vision_amd as sva
+    from sudoku_vision_amd import host
+    frames, corners, _ = _frames(64, 1080, 1920, seed=77)
+    minv = ctx.minv_to_device(sva.Context.corners_to_minv(corners))
+    rec_bytes = host.sparse_bits_record_bytes(1080, 1920, 1080 * 60 // 3)
+
+    def once():
+        b = ctx.preprocess(frames)
+        bits = ctx.preprocess_bits(frames)
+        filt = ctx.despeckle_bits(bits.clone())
+        rec = ctx.pack_sparse_bits(filt, torch.zeros((64, rec_bytes), dtype=torch.uint8, device="cuda")).clone()
+        cells = ctx.warp_cells(frames, minv)
+        return b, bits, filt, rec, cells
+
+    first = once()
+    for _ in range(3):
+        for a, b in zip(first, once()):
+            assert torch.equal(a, b)
+
+
 def test_cnn_is_deterministic():
     """The same batch twice gives the same bits, for every kernel family of the product, at batch sizes where two workgroups share a CU (600 and
     2,000 cells for the two-cells-per-workgroup bf16 conv kernel) -- round 3 found the bf16 configuration's logits varying from run to run in the

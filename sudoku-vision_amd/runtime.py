@@ -121,7 +121,7 @@ class Context:
     CONV_ALGO_NAMES = {0: "k_conv_features_pc + k_fc_head (direct implicit GEMM, f32 MFMA)",
                        2: "k_conv_features_wstream (Winograd F(2x2,3x3), f32 MFMA; cross-check build)",
                        3: "k_conv_features_wsplit (Winograd, bf16 MFMA with 3-way operand split; cross-check build)",
-                       4: "k_conv_features_h2 + k_fc_head_h2 (f16 hi/lo operand pairs, f16 MFMA, f32 accumulation)"}
+                       4: "k_conv_features_h2 + k_fc_head_h2p (f16 hi/lo operand pairs, f16 MFMA, f32 accumulation)"}
 
     def conv_kernel_info(self):
         """Which conv/fc kernels this process launches and the matrix instructions they issue per cell (sv_conv_kernel_info)."""

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
     //   * A operands flow through a RING-slot register ring, one ds_read_b128 per slot, PF taps ahead of their MFMAs, across tile
     //     boundaries (the tile loop is fully unrolled: all ring indices are static and the lgkmcnt waits are counted exactly);
     //   * all three partial products of a channel tile go into ONE accumulator (f32 either way), double-buffered by tile parity;
-    //     the epilogue of tile j-1 (2x2 max, scale + bias, ReLU, hi/lo split, two stores) is 18 single instructions in the slots of taps 2-7.
+    //     the epilogue of tile j-1 (2x2 max, scale + bias, ReLU, hi/lo split, two stores) is 14 single instructions in the slots of taps 2-6.
     constexpr int PF = 5, RING = 6;
     uint4 ring_h[RING], ring_l[RING];
     // per-lane LDS offset of this wave's tile jj (window-in-tile, position dy/dx, k-group of the lane): loop-invariant, 7 registers
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
         }
         f32x4 acc[2][2];                                                        // [tile parity][t]
         float m0 = 0.f, m1 = 0.f, t0 = 0.f, t1 = 0.f;
-        unsigned h0 = 0, h1 = 0, hp = 0, lp = 0;
+        unsigned hp = 0, lp = 0;
         // one single-instruction piece of the epilogue of the tile whose sums sit in accumulator set `set` (tile index jp of this wave)
         auto epilogue = [&](int piece, int jp, int set) {
             const f32x4 &v0 = acc[set][0], &v1 = acc[set][1];
@@ -298,20 +298,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
             case 5: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(m1) : "s"(scale_inv), "v"(bias2_1)); break;
             case 6: asm volatile("v_max_f32 %0, 0, %0" : "+v"(m0)); break;
             case 7: asm volatile("v_max_f32 %0, 0, %0" : "+v"(m1)); break;
-            // split_h2 of both values, one instruction per slot: hi = f16(m), lo = f16(m - f32(hi))
-            case 8: asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(h0) : "v"(m0)); break;
-            case 9: asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(h1) : "v"(m1)); break;
-            case 10: asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(t0) : "v"(h0)); break;
-            case 11: asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(t1) : "v"(h1)); break;
-            case 12: asm volatile("v_sub_f32 %0, %1, %0" : "+v"(t0) : "v"(m0)); break;
-            case 13: asm volatile("v_sub_f32 %0, %1, %0" : "+v"(t1) : "v"(m1)); break;
-            case 14: asm volatile("v_pack_b32_f16 %0, %1, %2" : "=v"(hp) : "v"(h0), "v"(h1)); break;
-            case 15: asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(t0), "v"(t1)); break;
-            case 16:                                                            // rows 4q..4q+3 = the 4 positions of window 4*(par + 2jp) + q
+            // split_h2 of both values in four instructions: both hi parts by one packed conversion, m - f32(hi) by v_fma_mix_f32 (the f16 half of
+            // hp widened exactly, times -1, plus m: one rounding, the same as the subtraction), both lo parts by another packed conversion
+            case 8: asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(m0), "v"(m1)); break;
+            case 9: asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(hp), "v"(m0)); break;
+            case 10: asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(hp), "v"(m1)); break;
+            case 11: asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(t0), "v"(t1)); break;
+            case 12:                                                            // rows 4q..4q+3 = the 4 positions of window 4*(par + 2jp) + q
                 if (jp < 6 || q == 0) *(unsigned *)(fcell + jp * 2048 + out_off) = hp;
                 break;
-            default:
+            case 13:
                 if (jp < 6 || q == 0) *(unsigned *)(fcell + jp * 2048 + out_off + 16) = lp;
+                break;
+            default: break;                                                     // (the slot structure offers 15 pieces)
             }
         };
         // 13 M tiles of 4 pooling windows; this wave takes tiles par, par+2, ... for its 32 channels
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
                 const h8 ah = __builtin_bit_cast(h8, ring_h[st % RING]), al = __builtin_bit_cast(h8, ring_l[st % RING]);
                 const h8 bh0 = __builtin_bit_cast(h8, breg[tap][0][0]), bl0 = __builtin_bit_cast(h8, breg[tap][0][1]);
                 const h8 bh1 = __builtin_bit_cast(h8, breg[tap][1][0]), bl1 = __builtin_bit_cast(h8, breg[tap][1][1]);
-                const int e0 = (jj > 0 && tap >= 2 && tap <= 7) ? 3 * (tap - 2) : -1;   // epilogue pieces e0, e0+1, e0+2 in this tap
+                const int e0 = (jj > 0 && tap >= 2 && tap <= 6 && 3 * (tap - 2) < 14) ? 3 * (tap - 2) : -1;   // epilogue pieces e0, e0+1, e0+2 in this tap
                 // slot 1
                 SV_SLOT();
                 if (tap == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[set][0]) : "v"(ah), "v"(bh0));
@@ -362,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_features_h2(const void *__restr
         if (ntile > 0) {
             asm volatile("s_nop 15\n\ts_nop 15");                              // the last tile's accumulators: MFMA -> VALU read distance
 #pragma unroll
-            for (int piece = 0; piece < 18; piece++) epilogue(piece, ntile - 1, (ntile - 1) & 1);
+            for (int piece = 0; piece < 14; piece++) epilogue(piece, ntile - 1, (ntile - 1) & 1);
         }
         SV_STAMP(2);
         __syncthreads();                                                        // (B_{k+1}) / (C)

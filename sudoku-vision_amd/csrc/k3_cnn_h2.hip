@@ -19,9 +19,13 @@
 //        position).  conv2 as an implicit GEMM: M = 4 pooling windows x 4 positions (so that the 4 accumulator registers of a
 //        lane are one pooling window: bias + ReLU + max never leave the lane), N = 2 x 16 channels per wave, K = 9 taps x 32
 //        channels; 3 MFMAs per (tap, N tile).  A wave keeps its 9 x 2 x 2 B operands in 144 VGPRs.
-//   k_fc_head_h2 : fc1 (3136 -> 128) with cells as M (one 16-cell tile per wave, 64 cells per workgroup); the 1.6 MB weight
-//        image (hi and lo halves) is staged once per workgroup through double-buffered LDS, features are read as f32 from
-//        global memory and split in registers; fc2 + argmax + softmax[argmax] epilogue in f32 (pipeline/run.py:139-143).
+//        The pooled, ReLU'd features leave the kernel already split into f16 pairs, 16 B of hi parts and 16 B of lo parts per
+//        group of 8: what the fc kernels' MFMAs take as they stand.
+//   k_fc_head_h2p : fc1 (3136 -> 128) with cells as M, one workgroup per CU (12 waves = 6 M tiles x 2 N halves), the 1.6 MB weight
+//        image (hi and lo halves) streamed once per CU, weights and features global -> LDS by DMA; fc2 + argmax + softmax[argmax]
+//        epilogue in f32 (pipeline/run.py:139-143).  Serves every batch whose share per CU fits a 96-cell pass.
+//   k_fc_head_h2  : round 2's form (one 16-cell tile per wave, 64 cells per workgroup, the weight image staged once per workgroup
+//        through double-buffered LDS, A fragments straight from global memory) for larger batches.
 //
 // Range: inputs and activations are carried as f16 pairs, so their magnitudes must stay below 65,504 (and a pair holds 22 significant bits
 // only while its low half is a normal f16; below that the absolute error is f16's subnormal step, 2^-24).  sv_load_weights_f32 bounds the

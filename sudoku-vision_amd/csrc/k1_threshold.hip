@@ -115,6 +115,19 @@ __device__ __forceinline__ float lane_next(float v)   // value held by lane+1
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
 __device__ __forceinline__ u32 lane_next_u32(u32 v) { return __float_as_uint(lane_next(__uint_as_float(v))); }
+// (value of `a` held by lane-1 / lane+1) + b, in one instruction (lanes past the wave's ends read 0, as lane_prev / lane_next)
+__device__ __forceinline__ float add_prev(float a, float b)
+{
+    float r;
+    asm("v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float add_next(float a, float b)
+{
+    float r;
+    asm("v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 __device__ __forceinline__ float gray_f32(float b, float g, float r)
 {
@@ -359,12 +372,13 @@ __device__ __forceinline__ void march_item(const u8 *__restrict__ bgr, int H, in
             const float q1 = lane_prev(p1), q2 = lane_prev(p2);
             if (cx0 == W) { p0 = q2; p1 = q1; }
         }
-        const float l2 = lane_prev(p2), l3 = lane_prev(p3), r0 = lane_next(p0), r1 = lane_next(p1);
+        // the neighbour lanes' pixels enter as DPP operands of the sums they belong to (six v_add_f32_dpp; as values of their own, the two that
+        // are used twice, l3 and r0, each cost a v_mov_b32_dpp on top)
         f32x4_t h;
-        h[0] = blur5(l2, l3, p0, p1, p2);
-        h[1] = blur5(l3, p0, p1, p2, p3);
-        h[2] = blur5(p0, p1, p2, p3, r0);
-        h[3] = blur5(p1, p2, p3, r0, r1);
+        h[0] = __builtin_fmaf(6.f, p0, __builtin_fmaf(4.f, add_prev(p3, p1), add_prev(p2, p2)));      // blur5(l2, l3, p0, p1, p2)
+        h[1] = __builtin_fmaf(6.f, p1, __builtin_fmaf(4.f, p0 + p2, add_prev(p3, p3)));               // blur5(l3, p0, p1, p2, p3)
+        h[2] = __builtin_fmaf(6.f, p2, __builtin_fmaf(4.f, p1 + p3, add_next(p0, p0)));               // blur5(p0, p1, p2, p3, r0)
+        h[3] = __builtin_fmaf(6.f, p3, __builtin_fmaf(4.f, add_next(p0, p2), add_next(p1, p1)));      // blur5(p1, p2, p3, r0, r1)
         return h;
     };
     // blurred row (as f32) from the 5-row window, with the horizontal REPLICATE of the blurred image, and its f32 row pass

@@ -32,6 +32,14 @@ __global__ __launch_bounds__(256) void k(float *out, int n)
                 if (KIND == 12) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7]));
                 if (KIND == 13) asm volatile("v_rndne_f32 %0, %0" : "+v"(f[i]));
                 if (KIND == 14) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(*(double *)&f[i & 6]) : "v"(*(double *)&f[(i + 2) & 6]));
+                // round 3: the integer multiplies and the fp64 operations K2 is made of
+                if (KIND == 15) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+                if (KIND == 16) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+                if (KIND == 17) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(*(unsigned long long *)&u[i & 6]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 3) & 7]) : "vcc");
+                if (KIND == 18) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(*(double *)&f[i & 6]) : "v"(*(double *)&f[(i + 2) & 6]));
+                if (KIND == 19) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*(double *)&f[i & 6]) : "v"(*(double *)&f[(i + 2) & 6]));
+                if (KIND == 20) asm volatile("v_rcp_f64 %0, %0" : "+v"(*(double *)&f[i & 6]));
+                if (KIND == 21) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(*(unsigned long long *)&u[i & 6]) : "v"(*(unsigned long long *)&u[(i + 2) & 6]));
             }
     }
     float s = 0; unsigned t = 0;
@@ -58,11 +66,13 @@ void run(const char *name, float *d, int waves_per_simd)
 int main()
 {
     float *d; hipMalloc(&d, 256 * 8 * 256 * sizeof(float) * 4);
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {2, 4}) {
         run<0>("v_add_f32", d, w); run<1>("v_mul_f32", d, w); run<2>("v_fma_f32", d, w); run<3>("v_add_u32", d, w);
         run<4>("v_mad_u32_u24", d, w); run<5>("v_bfe_u32", d, w); run<6>("v_lshl_or_b32", d, w); run<7>("v_cvt_f32_ubyte1", d, w);
         run<8>("v_pk_add_f32", d, w); run<9>("v_pk_mul_f32", d, w); run<10>("v_perm_b32", d, w); run<11>("v_dot4_u32_u8", d, w);
         run<12>("v_add3_u32", d, w); run<13>("v_rndne_f32", d, w); run<14>("v_pk_fma_f32", d, w);
+        run<15>("v_mul_lo_u32", d, w); run<16>("v_mul_u32_u24", d, w); run<17>("v_mad_u64_u32", d, w); run<18>("v_fma_f64", d, w);
+        run<19>("v_mul_f64", d, w); run<20>("v_rcp_f64", d, w); run<21>("v_lshl_add_u64", d, w);
         printf("\n");
     }
     return 0;

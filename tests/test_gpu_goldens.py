@@ -313,7 +313,9 @@ def test_bench_configs3_full_size(ctx):
         assert res["kernels"][k]["launches"] == launches, k
     assert res["value_kind"] == "end_to_end" and res["end_to_end_with_host_corner_search"]["grids_found"] == 256
     ref = _bench(["--steps", "40", "--warmup", "10", "--no-e2e", "--no-cpu-baseline"])
-    assert abs(res["per_gpu_value_device_only"] / ref["value"] - 1) <= 0.05, (res["per_gpu_value_device_only"], ref["value"])
+    # (two separate runs: the same binary measures up to 5 % apart minutes apart on one box -- K1 0.594 vs 0.625 ms in profiles/r03_i -- so the bound
+    # is 10 %; it is there to catch a workload that is not the one it says it is)
+    assert abs(res["per_gpu_value_device_only"] / ref["value"] - 1) <= 0.10, (res["per_gpu_value_device_only"], ref["value"])
 
 
 def test_degenerate_quad_does_not_abort_the_batch(ctx, golden_dir, monkeypatch):
